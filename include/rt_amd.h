@@ -1,0 +1,251 @@
+/* rt_amd.h -- C-ABI of the MI355X path-tracing core.
+ *
+ * This is the drop-in boundary for the hot path of droune2001/ray_tracing:
+ * the recursive color() (reference src/main.cpp:91-127) driven by the
+ * thread_pool render loop (src/main.cpp:203-256, 543-561) and the resolve
+ * step (src/main.cpp:708-743).  The reference has no FFI layer; the seam is
+ * the argument set handed to compute_one_sample_task (src/main.cpp:545-554):
+ * world (BVH root), important_hitables, camera, image size, sub_samples,
+ * max_depth, shared_buffer.  The host keeps the reference scene API
+ * (ray_tracing_amd/host/rt_scene_api.h mirrors scenes.h, hitable.h, bvh.h,
+ * camera.h, material.h, texture.h, pdf.h) and flattens the object tree into the
+ * plain arrays below; everything from ray generation to the accumulated
+ * float4 image then runs on the GPU.
+ *
+ * Rules of the boundary
+ *   - extern "C", plain pointers and sizes only; no C++ or torch types.
+ *   - Every call returns RT_OK (0) or a negative rt_status; rt_last_error()
+ *     returns a thread-local message for the last failure.  Nothing throws.
+ *   - The caller owns every host array passed in; rt_scene_create copies them
+ *     to the device and owns that copy until rt_scene_destroy.
+ *   - Pointers named d_* are DEVICE pointers (hipMalloc / torch CUDA tensors);
+ *     all other pointers are host pointers.
+ *   - `stream` arguments are a hipStream_t passed as void* (NULL = default).
+ *   - There is no CPU fallback: without a HIP device every compute entry point
+ *     fails with RT_ERR_NO_DEVICE.
+ */
+#ifndef RT_AMD_H_
+#define RT_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / inconsistent scene description */
+    RT_ERR_NO_DEVICE = -2,   /* no HIP device, or a HIP call failed           */
+    RT_ERR_UNSUPPORTED = -3, /* scene composition the flattener cannot express */
+    RT_ERR_NOMEM = -4
+} rt_status;
+
+/* ------------------------------------------------------------------ */
+/* Flattened scene                                                      */
+/* ------------------------------------------------------------------ */
+
+/* One step of the depth-first walk of the reference's bvh_node tree
+ * (src/bvh.h:123-163 visits left then right, always both).  Entries are stored
+ * in pre-order.  An inner entry carries the node's aabb and `skip`, the index
+ * of the first entry after its subtree, taken when aabb::hit
+ * (src/aabb.h:60-83) fails.  A leaf entry names a primitive.  Two 16-byte
+ * halves so a lane fetches one entry with two dwordx4 loads. */
+typedef struct rt_entry {
+    float   lo[3];  /* inner: box min                                          */
+    int32_t a;      /* inner: skip index; leaf: primitive index                */
+    float   hi[3];  /* inner: box max                                          */
+    int32_t b;      /* bits 0-7 rt_entry_kind, bits 8-31 chain index of the
+                       space this entry is expressed in                        */
+} rt_entry;
+
+enum rt_entry_kind { RT_ENTRY_INNER = 0, RT_ENTRY_LEAF = 1 };
+
+/* Primitive kinds.  Values are part of the ABI. */
+enum rt_prim_kind {
+    RT_PRIM_SPHERE = 0,        /* src/sphere.h:21-59    f = cx cy cz r                  */
+    RT_PRIM_MOVING_SPHERE = 1, /* src/sphere.h:147-183  f = c0xyz c1xyz r t0 t1         */
+    RT_PRIM_XY_RECT = 2,       /* src/plane.h:9-29      f = a0 a1 b0 b1 k  (x0 x1 y0 y1 z) */
+    RT_PRIM_XZ_RECT = 3,       /* src/plane.h:47-67     f = x0 x1 z0 z1 y               */
+    RT_PRIM_YZ_RECT = 4,       /* src/plane.h:109-129   f = y0 y1 z0 z1 x               */
+    RT_PRIM_GROUP = 5,         /* hitable_list / box: src/hitable_list.h:18-34, src/box.h:7-23;
+                                  children = prims[first .. first+count)                */
+    RT_PRIM_MEDIUM = 6         /* constant_medium src/volume.h:23-53; first = boundary
+                                  primitive, f[0] = density, material = isotropic       */
+};
+
+#define RT_PRIM_FLIP 1u     /* odd number of flip_normals wrappers (src/hitable.h:27-38) */
+#define RT_PRIM_NEEDS_UV 2u /* material's texture reads (u,v): compute them on a hit     */
+
+typedef struct rt_prim {
+    int32_t kind;     /* rt_prim_kind                                           */
+    uint32_t flags;   /* RT_PRIM_*                                              */
+    int32_t material; /* index into materials (-1 for GROUP)                    */
+    int32_t chain;    /* instance chain from world space to this primitive      */
+    int32_t first;    /* GROUP: first child; MEDIUM: boundary primitive         */
+    int32_t count;    /* GROUP: number of children                              */
+    int32_t user_id;  /* stable id: ordinal of this leaf in the depth-first walk
+                         of the final tree (what rt_trace_rays reports)         */
+    int32_t reserved;
+    float   f[12];    /* parameters, layout per kind (see rt_prim_kind)         */
+} rt_prim;            /* 80 bytes                                               */
+
+/* Instance transforms (src/transforms.h).  A chain lists the operations in the
+ * order a ray meets them going down the tree, outermost first. */
+enum rt_xform_kind { RT_XFORM_TRANSLATE = 0, RT_XFORM_ROTATE_Y = 1 };
+typedef struct rt_xform {
+    int32_t kind;
+    float   a, b, c; /* TRANSLATE: offset xyz.  ROTATE_Y: a = sin_theta, b = cos_theta */
+} rt_xform;
+typedef struct rt_chain {
+    int32_t first, count; /* xforms[first .. first+count); chain 0 is the identity */
+} rt_chain;
+
+enum rt_material_kind { /* src/material.h */
+    RT_MAT_LAMBERTIAN = 0,
+    RT_MAT_METAL = 1,
+    RT_MAT_DIELECTRIC = 2,
+    RT_MAT_DIFFUSE_LIGHT = 3,
+    RT_MAT_ISOTROPIC = 4
+};
+typedef struct rt_material {
+    int32_t kind;
+    int32_t texture; /* albedo / emit texture, -1 for dielectric */
+    float   p0;      /* metal: fuzz (already clamped to <= 1); dielectric: ref_idx */
+    int32_t reserved;
+} rt_material;
+
+enum rt_texture_kind { /* src/texture.h */
+    RT_TEX_CONSTANT = 0,
+    RT_TEX_CHECKER = 1, /* a = odd texture, b = even texture */
+    RT_TEX_NOISE = 2,   /* scale; perlin gradient table is built into the library */
+    RT_TEX_IMAGE = 3    /* texels[offset ..), nx * ny * 3 bytes RGB */
+};
+typedef struct rt_texture {
+    int32_t kind;
+    int32_t a, b;
+    int32_t nx, ny;
+    int32_t reserved;
+    int64_t offset;
+    float   color[3];
+    float   scale;
+} rt_texture; /* 48 bytes */
+
+/* camera block = the members camera::camera computes (src/camera.h:29-52) */
+typedef struct rt_camera {
+    float origin[3];
+    float u[3], v[3], w[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float lens_radius;
+    float time0, time1;
+} rt_camera;
+
+typedef struct rt_scene_desc {
+    uint32_t struct_size; /* sizeof(rt_scene_desc) */
+    uint32_t abi_version; /* RT_ABI_VERSION        */
+    const rt_entry*    entries;   int32_t n_entries;
+    const rt_prim*     prims;     int32_t n_prims;
+    const rt_xform*    xforms;    int32_t n_xforms;
+    const rt_chain*    chains;    int32_t n_chains;   /* chains[0] = identity */
+    const rt_material* materials; int32_t n_materials;
+    const rt_texture*  textures;  int32_t n_textures;
+    const uint8_t*     texels;    int64_t n_texel_bytes;
+    /* important_hitables (src/main.cpp:107, src/hitable_list.h:67-88): primitive
+     * indices; -1 marks a member whose type has no pdf_value/random override
+     * (src/hitable.h:19-20: pdf 0, direction (1,0,0)). */
+    const int32_t*     lights;    int32_t n_lights;
+    rt_camera camera;
+} rt_scene_desc;
+
+typedef struct rt_scene rt_scene; /* opaque, device-resident */
+
+/* Replaces: `cornell_box(&world,&important,&cam,aspect)` + `new bvh_node(...)`
+ * hand-off to the render tasks (src/main.cpp:505-511, 545-554).  `device` is
+ * the HIP device ordinal.  Validates every index in the description. */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* ------------------------------------------------------------------ */
+/* Render                                                               */
+/* ------------------------------------------------------------------ */
+
+typedef struct rt_render_params {
+    uint32_t struct_size;
+    int32_t  nx, ny;        /* image_width, image_height (src/main.cpp:546-547)        */
+    int32_t  sample_begin;  /* first sample index of this call (sample_id, :549)       */
+    int32_t  sample_end;    /* one past the last; GPU g of G gets a disjoint range      */
+    int32_t  sub_samples;   /* -S, src/main.cpp:228                                     */
+    int32_t  max_depth;     /* -r, src/main.cpp:98                                      */
+    uint32_t seed;          /* key of the counter-based per-path RNG (include/rt_rng.h) */
+    uint32_t flags;         /* RT_RENDER_*                                              */
+} rt_render_params;
+
+#define RT_RENDER_ACCUMULATE 1u /* add into d_accum instead of overwriting it */
+
+/* Replaces the loop `for i<ns: addTask(compute_one_sample_task)`, pool->finish()
+ * (src/main.cpp:543-561) for samples [sample_begin, sample_end).
+ * d_accum: device float[ny][nx][4], per pixel [A, B, G, R] exactly as
+ * compute_one_sample_task writes it (src/main.cpp:238-242; row 0 = image top),
+ * but holding SUMS over the samples of this call: A = number of samples,
+ * B/G/R = sum over samples of the sub-sample average of de_nan(color()).
+ * Asynchronous on `stream`; the buffer is ready when the stream is. */
+int rt_render(rt_scene* scene, const rt_render_params* params, float* d_accum, void* stream);
+
+/* Replaces the resolve loop (src/main.cpp:708-743): per pixel sum / total
+ * samples (taken from the A channel), sqrtf gamma, clamp01, (unsigned)(c*255.99f),
+ * packed 0xff000000 | b<<16 | g<<8 | r.  d_rgba8: device uint32[ny][nx]. */
+int rt_resolve(const float* d_accum, int32_t nx, int32_t ny, uint32_t* d_rgba8, void* stream);
+
+/* Convenience for callers without their own device buffers: render
+ * [sample_begin, sample_end) and copy the float accumulators (and, when
+ * h_rgba8 is not NULL, the resolved 8-bit image) to HOST memory. Blocking. */
+int rt_render_to_host(rt_scene* scene, const rt_render_params* params, float* h_accum,
+                      uint32_t* h_rgba8);
+
+/* ------------------------------------------------------------------ */
+/* Closest-hit queries (the parity surface)                             */
+/* ------------------------------------------------------------------ */
+
+/* camera::get_ray (src/camera.h:54-68) for n samples, with the random inputs
+ * made explicit: h_st = n pairs (s,t); h_lens = n pairs of unit-disk points or
+ * NULL (= (0,0)); h_time01 = n numbers in [0,1) or NULL (= 0).
+ * h_rays_out: n x 7 floats (origin xyz, direction xyz, time). */
+int rt_camera_rays(rt_scene* scene, int32_t n, const float* h_st, const float* h_lens,
+                   const float* h_time01, float* h_rays_out);
+
+typedef struct rt_hit {
+    int32_t prim_id;  /* rt_prim.user_id of the closest primitive, -1 on a miss */
+    int32_t material; /* material index, -1 on a miss                           */
+    float   t;
+    float   u, v;     /* 0 unless the primitive sets them                       */
+    float   p[3];
+    float   normal[3];
+    float   reserved;
+} rt_hit; /* 48 bytes */
+
+/* hitable::hit on the world (src/main.cpp:94: world->hit(r, 0.001f, FLT_MAX, rec))
+ * for n rays of 7 floats each.  `seed` keys the draws constant_medium::hit
+ * makes (src/volume.h:43); it is unused for scenes without media. */
+int rt_trace_rays(rt_scene* scene, int32_t n, const float* h_rays, float t_min, float t_max,
+                  uint32_t seed, rt_hit* h_hits_out);
+
+/* ------------------------------------------------------------------ */
+/* Misc                                                                 */
+/* ------------------------------------------------------------------ */
+const char* rt_last_error(void);
+int rt_abi_version(void);
+/* Number of HIP devices visible, or a negative rt_status. */
+int rt_device_count(void);
+/* Timing of the most recent rt_render on this scene: milliseconds between HIP
+ * events recorded on the render stream around the path-tracing kernel.
+ * Blocks until that kernel has finished. */
+int rt_last_render_ms(rt_scene* scene, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H_ */

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/ from the REAL reference (oracle/_ref/ref_harness).
+
+Runs in the build container only (needs /root/reference to build the harness:
+`make -C oracle ref`).  Every number in tests/golden/ is an output of the
+reference's own code; see oracle/ref_harness_tail.cpp for what each mode calls.
+The fixtures are inputs and expected outputs (data), not source.
+
+    python oracle/make_golden.py            # everything except the slow converged image
+    python oracle/make_golden.py --image    # + Cornell 256x256 at 4096 spp (about 8 minutes)
+"""
+import argparse
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "..", "tests", "golden")
+HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+
+
+def run(*args):
+    cmd = [HARNESS] + [str(a) for a in args]
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--image", action="store_true", help="also render the 4096-spp converged image")
+    ap.add_argument("--scenes", default="cornell_box")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        for scene in a.scenes.split(","):
+            out = {}
+            # per-sample float buffers of a `-t 1` run: (ns, ny, nx, 4) = [1,b,g,r]
+            run("samples", scene, 64, 64, 4, 1, 50, f"{tmp}/s.npy")
+            out["samples_64x64_s4_S1_r50"] = np.load(f"{tmp}/s.npy")
+            run("samples", scene, 48, 32, 2, 2, 5, f"{tmp}/s.npy")
+            out["samples_48x32_s2_S2_r5"] = np.load(f"{tmp}/s.npy")
+            # primary rays through pixel centres: see ref_harness_tail.cpp mode_hits for the 20 columns
+            run("hits", scene, 128, 128, f"{tmp}/h.npy")
+            out["hits_128x128"] = np.load(f"{tmp}/h.npy")
+            run("hits", scene, 200, 120, f"{tmp}/h.npy")
+            out["hits_200x120"] = np.load(f"{tmp}/h.npy")
+            np.savez_compressed(os.path.join(GOLD, f"{scene}.npz"), **out)
+            run("tree", scene, os.path.join(GOLD, f"{scene}_tree.txt"))
+            if a.image:
+                run("image", scene, 256, 256, 4096, 50, f"{tmp}/i.npy")
+                np.save(os.path.join(GOLD, f"{scene}_256x256_4096spp_r50.npy"), np.load(f"{tmp}/i.npy"))
+        os.makedirs(f"{tmp}/kat")
+        run("kat", f"{tmp}/kat")
+        kat = {f[:-4]: np.load(f"{tmp}/kat/{f}") for f in sorted(os.listdir(f"{tmp}/kat"))}
+        np.savez_compressed(os.path.join(GOLD, "kat.npz"), **kat)
+    print("wrote", sorted(os.listdir(GOLD)))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
