@@ -386,6 +386,12 @@ static int mode_kat(int argc, char **argv)
             int axis = i % 3;
             vec3 o(U(-2, 2), U(-2, 2), U(-2, 2)), d(U(-1, 1), U(-1, 1), U(-1, 1));
             float a0 = U(-1, 0), a1 = U(0, 1), b0 = U(-1, 0), b1 = U(0, 1), k = U(-1, 1);
+            if (i % 4 != 0) { // aim most rays at (or just around) the rectangle
+                float ta = U(-1.3f, 1.3f), tb = U(-1.3f, 1.3f);
+                vec3 target = axis == 0 ? vec3(ta, tb, k) : axis == 1 ? vec3(ta, k, tb) : vec3(k, ta, tb);
+                d = target - o;
+                if (i % 8 == 1) d = d * U(0.1f, 4.0f);
+            }
             float t0 = (i & 1) ? 0.001f : -FLT_MAX, t1 = FLT_MAX;
             hit_record rec = {};
             bool h;

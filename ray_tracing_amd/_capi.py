@@ -117,6 +117,11 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise OSError(f"{LIB_PATH} is missing: build it with `make -C ray_tracing_amd` "
                           "(or python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and librt_amd.so asks for
+        # the same SONAME.  Importing torch first makes the loader hand librt_amd.so torch's copy, so
+        # device pointers and streams can be shared; loaded the other way round the process would hold
+        # two runtimes and torch would find no GPU.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)

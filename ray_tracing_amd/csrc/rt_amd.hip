@@ -1,0 +1,524 @@
+// rt_amd.hip -- kernels and C-ABI entry points of include/rt_amd.h (gfx950).
+//
+// Kernels
+//   render_kernel   the per-pixel Monte Carlo loop: replaces compute_one_sample_task::run
+//                   (src/main.cpp:217-245) + color() (src/main.cpp:91-127) + the thread pool.
+//   resolve_kernel  src/main.cpp:708-743.
+//   trace_kernel    world->hit() for a batch of rays (the parity surface).
+//   camera_kernel   camera::get_ray for a batch of samples.
+//
+// render_kernel: one wave64 owns one task = (8x8 pixel tile, range of samples).
+// The wave keeps 64 paths in registers, one per lane.  Each iteration of its loop
+//   1. refills dead lanes from the task's pool of (pixel, sample) items: a ballot of
+//      the dead lanes, a prefix count (mbcnt) to give each a distinct item, ray
+//      generation for those lanes (live paths stay packed in the wave, so the wave
+//      never runs half empty while the pool has work);
+//   2. traces all 64 rays through the scene with the wave-uniform scan of
+//      rt_device.hpp (scene data in SGPRs);
+//   3. shades: emission, scatter, mixture-pdf importance sampling, throughput update;
+//      finished paths add their radiance to the tile's accumulators in LDS.
+// When the pool is empty and every lane is dead the 64 pixel sums go to HBM, once.
+// HBM traffic is therefore 16 B per pixel per task; everything else lives in
+// registers, SGPRs and 1 KiB of LDS per wave.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rt_device.hpp"
+#include "rt_error.h"
+
+using namespace rt;
+
+namespace {
+
+struct RenderArgs {
+    int32_t nx, ny;
+    int32_t tiles_x, tiles_y;
+    int32_t sample_begin;
+    int32_t chunk_samples; // samples per task
+    int32_t n_chunks;
+    int32_t n_samples;     // sample_end - sample_begin
+    int32_t sub_samples, max_depth;
+    uint32_t seed;
+    int32_t atomic_out;    // 1: add into accum with atomics (several tasks per pixel or ACCUMULATE)
+    int32_t n_tasks;
+};
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S, RenderArgs A, float *__restrict__ accum)
+{
+    __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (task >= A.n_tasks) return; // whole wave leaves; no block-level barrier is used below
+
+    // task -> tile and sample chunk.  Consecutive tasks are consecutive chunks of one tile.
+    const int tile = task / A.n_chunks, chunk = task - tile * A.n_chunks;
+    const int tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
+    const int s0 = chunk * A.chunk_samples;
+    const int s1 = min(s0 + A.chunk_samples, A.n_samples);
+    const int total = 64 * (s1 - s0) * A.sub_samples; // items in the pool; item = q * 64 + pixel-in-tile
+
+    float *acc = tile_acc[wave];
+    acc[lane] = 0.0f, acc[64 + lane] = 0.0f, acc[128 + lane] = 0.0f;
+
+    int next = 0; // wave-uniform pool cursor
+    bool alive = false;
+    Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
+    V3 T = v3(1, 1, 1);
+    Rng rng{0u, 0u};
+    int depth = 0, pix = lane;
+
+    for (;;) {
+        // ---- 1. refill dead lanes (ballot + prefix count) ----------------------
+        const unsigned long long dead = __ballot(!alive);
+        if (dead != 0ull && next < total) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+            const int item = next + rank;
+            if (!alive && item < total) {
+                pix = item & 63;
+                const int q = item >> 6;
+                const int sample = A.sample_begin + s0 + q / A.sub_samples;
+                const int sub = q - (q / A.sub_samples) * A.sub_samples;
+                const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3); // row 0 = image top
+                if (col < A.nx && row < A.ny) {
+                    rng.key = rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub));
+                    rng.n = 0;
+                    // compute_one_sample_task::run, src/main.cpp:230-233; j counts rows from the bottom
+                    const int j = A.ny - 1 - row;
+                    const float u = float(col + rng.next()) / float(A.nx);
+                    const float v = float(j + rng.next()) / float(A.ny);
+                    const V3 disk = random_in_unit_disk(rng);
+                    const float time01 = rng.next();
+                    r = camera_ray(S.cam, u, v, disk, time01);
+                    T = v3(1, 1, 1);
+                    depth = 0;
+                    alive = true;
+                }
+            }
+            next += __popcll(dead);
+        }
+        if (!__any(alive)) {
+            if (next >= total) break;
+            continue; // only out-of-image pixels were drawn; draw again
+        }
+
+        // ---- 2. closest hit ------------------------------------------------------
+        Hit h;
+        const bool hit_any = world_hit(S, r, 0.001f, RT_FLT_MAX, alive, rng, h);
+
+        // ---- 3. shade -------------------------------------------------------------
+        if (alive) {
+            V3 L;
+            if (!shade(S, hit_any, h, r, T, depth, A.max_depth, rng, L)) {
+                alive = false;
+                // de_nan, src/vec3.h:184-191
+                if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
+                if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
+                if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[128 + pix], L.z);
+            }
+        }
+    }
+
+    // ---- tile sums -> HBM: [A, B, G, R] per pixel (src/main.cpp:238-242) ---------
+    const int col = tile_x * 8 + (lane & 7), row = tile_y * 8 + (lane >> 3);
+    if (col < A.nx && row < A.ny) {
+        const float inv = 1.0f / (float)A.sub_samples; // col /= sub_samples, src/main.cpp:236
+        float4 o = make_float4((float)(s1 - s0), acc[128 + lane] * inv, acc[64 + lane] * inv, acc[lane] * inv);
+        float *dst = accum + 4 * ((size_t)row * A.nx + col);
+        if (A.atomic_out) {
+            atomicAdd(dst + 0, o.x), atomicAdd(dst + 1, o.y), atomicAdd(dst + 2, o.z), atomicAdd(dst + 3, o.w);
+        } else {
+            *reinterpret_cast<float4 *>(dst) = o;
+        }
+    }
+}
+
+// src/main.cpp:708-743
+__global__ void resolve_kernel(const float4 *__restrict__ accum, int n, uint32_t *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = accum[i]; // A B G R
+    float inv = 1.0f / (float)(int)a.x;
+    float c[3] = {sqrtf(a.w * inv), sqrtf(a.z * inv), sqrtf(a.y * inv)};
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        float x = c[k];
+        if (x < 0.0f) x = 0.0f;
+        if (x > 1.0f) x = 1.0f;
+        q[k] = (uint32_t)(x * 255.99f);
+    }
+    out[i] = 0xff000000u | (q[2] << 16) | (q[1] << 8) | q[0];
+}
+
+__global__ __launch_bounds__(256) void trace_kernel(DevScene S, int n, const float *__restrict__ rays, float t_min, float t_max,
+                                                    uint32_t seed, rt_hit *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool alive = i < n;
+    int k = alive ? i : 0;
+    const float *f = rays + 7 * (size_t)k;
+    Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
+    Rng rng{rt_path_key(seed, (uint32_t)k, 0u), 0u};
+    Hit h;
+    bool any = world_hit(S, r, t_min, t_max, alive, rng, h);
+    if (!alive) return;
+    rt_hit o;
+    o.prim_id = any ? S.prims[h.prim].user_id : -1;
+    o.material = any ? h.material : -1;
+    o.t = any ? h.t : 0.0f, o.u = any ? h.u : 0.0f, o.v = any ? h.v : 0.0f;
+    o.p[0] = any ? h.p.x : 0.0f, o.p[1] = any ? h.p.y : 0.0f, o.p[2] = any ? h.p.z : 0.0f;
+    o.normal[0] = any ? h.n.x : 0.0f, o.normal[1] = any ? h.n.y : 0.0f, o.normal[2] = any ? h.n.z : 0.0f;
+    o.reserved = 0.0f;
+    out[i] = o;
+}
+
+__global__ void camera_kernel(rt_camera cam, int n, const float *__restrict__ st, const float *__restrict__ lens,
+                              const float *__restrict__ time01, float *__restrict__ rays)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 disk = lens ? v3(lens[2 * i], lens[2 * i + 1], 0.0f) : v3(0, 0, 0);
+    Ray r = camera_ray(cam, st[2 * i], st[2 * i + 1], disk, time01 ? time01[i] : 0.0f);
+    float *o = rays + 7 * (size_t)i;
+    o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z, o[6] = r.time;
+}
+
+} // namespace
+
+// ===========================================================================
+// host side of the C-ABI
+// ===========================================================================
+struct rt_scene {
+    int device = 0;
+    void *blob = nullptr; // one allocation holding every table
+    DevScene dev;
+    bool needs_uv_any = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+#define RT_HIP(call)                                                                                                   \
+    do {                                                                                                               \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "%s: %s", #call, hipGetErrorString(e_));                \
+    } while (0)
+
+static int validate(const rt_scene_desc *d)
+{
+    if (!d) return rt_fail(RT_ERR_INVALID, "rt_scene_create: null description");
+    if (d->struct_size != sizeof(rt_scene_desc) || d->abi_version != RT_ABI_VERSION)
+        return rt_fail(RT_ERR_INVALID, "rt_scene_create: description is for ABI %u size %u, library has ABI %d size %zu",
+                       d->abi_version, d->struct_size, RT_ABI_VERSION, sizeof(rt_scene_desc));
+    if (d->n_entries < 1 || !d->entries || d->n_prims < 1 || !d->prims || d->n_chains < 1 || !d->chains ||
+        d->n_materials < 1 || !d->materials || d->n_textures < 0 || d->n_xforms < 0 || d->n_lights < 0)
+        return rt_fail(RT_ERR_INVALID, "rt_scene_create: empty or missing table");
+    if (d->n_chains >= (1 << 23)) return rt_fail(RT_ERR_INVALID, "rt_scene_create: too many chains");
+    if (d->chains[0].count != 0) return rt_fail(RT_ERR_INVALID, "rt_scene_create: chain 0 must be the identity");
+    for (int i = 0; i < d->n_chains; ++i) {
+        const rt_chain &c = d->chains[i];
+        if (c.count < 0 || c.first < 0 || (c.count > 0 && (int64_t)c.first + c.count > d->n_xforms))
+            return rt_fail(RT_ERR_INVALID, "rt_scene_create: chain %d out of range", i);
+    }
+    for (int i = 0; i < d->n_xforms; ++i)
+        if (d->xforms[i].kind != RT_XFORM_TRANSLATE && d->xforms[i].kind != RT_XFORM_ROTATE_Y)
+            return rt_fail(RT_ERR_INVALID, "rt_scene_create: xform %d has unknown kind", i);
+    for (int i = 0; i < d->n_textures; ++i) {
+        const rt_texture &t = d->textures[i];
+        if (t.kind < RT_TEX_CONSTANT || t.kind > RT_TEX_IMAGE) return rt_fail(RT_ERR_INVALID, "rt_scene_create: texture %d has unknown kind", i);
+        if (t.kind == RT_TEX_CHECKER && (t.a < 0 || t.a >= d->n_textures || t.b < 0 || t.b >= d->n_textures))
+            return rt_fail(RT_ERR_INVALID, "rt_scene_create: checker texture %d refers outside the table", i);
+        if (t.kind == RT_TEX_IMAGE && (t.nx < 1 || t.ny < 1 || t.offset < 0 || !d->texels ||
+                                       t.offset + (int64_t)3 * t.nx * t.ny > d->n_texel_bytes))
+            return rt_fail(RT_ERR_INVALID, "rt_scene_create: image texture %d outside the texel blob", i);
+    }
+    for (int i = 0; i < d->n_materials; ++i) {
+        const rt_material &m = d->materials[i];
+        if (m.kind < RT_MAT_LAMBERTIAN || m.kind > RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "rt_scene_create: material %d has unknown kind", i);
+        if (m.kind != RT_MAT_DIELECTRIC && (m.texture < 0 || m.texture >= d->n_textures))
+            return rt_fail(RT_ERR_INVALID, "rt_scene_create: material %d has no texture", i);
+    }
+    auto plain = [](int k) { return k >= RT_PRIM_SPHERE && k <= RT_PRIM_YZ_RECT; };
+    for (int i = 0; i < d->n_prims; ++i) {
+        const rt_prim &p = d->prims[i];
+        if (p.kind < RT_PRIM_SPHERE || p.kind > RT_PRIM_MEDIUM) return rt_fail(RT_ERR_INVALID, "rt_scene_create: primitive %d has unknown kind", i);
+        if (p.chain < 0 || p.chain >= d->n_chains) return rt_fail(RT_ERR_INVALID, "rt_scene_create: primitive %d chain out of range", i);
+        if (p.kind == RT_PRIM_GROUP) {
+            if (p.count < 1 || p.first < 0 || (int64_t)p.first + p.count > d->n_prims)
+                return rt_fail(RT_ERR_INVALID, "rt_scene_create: group %d children out of range", i);
+            for (int k = 0; k < p.count; ++k) {
+                const rt_prim &c = d->prims[p.first + k];
+                if (!plain(c.kind) || c.material < 0 || c.material >= d->n_materials)
+                    return rt_fail(RT_ERR_INVALID, "rt_scene_create: group %d child %d must be a plain primitive with a material", i, k);
+            }
+        } else {
+            if (p.material < 0 || p.material >= d->n_materials)
+                return rt_fail(RT_ERR_INVALID, "rt_scene_create: primitive %d material out of range", i);
+            if (p.kind == RT_PRIM_MEDIUM) {
+                if (p.first < 0 || p.first >= d->n_prims || d->prims[p.first].kind == RT_PRIM_MEDIUM)
+                    return rt_fail(RT_ERR_INVALID, "rt_scene_create: medium %d has no usable boundary", i);
+                if (!(p.f[0] > 0.0f)) return rt_fail(RT_ERR_INVALID, "rt_scene_create: medium %d density must be positive", i);
+            }
+        }
+    }
+    for (int i = 0; i < d->n_entries; ++i) {
+        const rt_entry &e = d->entries[i];
+        int kind = e.b & 255, chain = e.b >> 8;
+        if (chain < 0 || chain >= d->n_chains) return rt_fail(RT_ERR_INVALID, "rt_scene_create: entry %d chain out of range", i);
+        if (kind == RT_ENTRY_INNER) {
+            // the skip link must move forward or the scan would never end
+            if (e.a <= i || e.a > d->n_entries) return rt_fail(RT_ERR_INVALID, "rt_scene_create: entry %d skip link %d is not ahead", i, e.a);
+        } else if (kind == RT_ENTRY_LEAF) {
+            if (e.a < 0 || e.a >= d->n_prims) return rt_fail(RT_ERR_INVALID, "rt_scene_create: entry %d primitive out of range", i);
+        } else {
+            return rt_fail(RT_ERR_INVALID, "rt_scene_create: entry %d has unknown kind", i);
+        }
+    }
+    for (int i = 0; i < d->n_lights; ++i) {
+        int l = d->lights[i];
+        if (l >= d->n_prims) return rt_fail(RT_ERR_INVALID, "rt_scene_create: light %d out of range", i);
+        if (l >= 0 && d->prims[l].kind != RT_PRIM_XZ_RECT && d->prims[l].kind != RT_PRIM_SPHERE)
+            return rt_fail(RT_ERR_INVALID, "rt_scene_create: light %d must be an xz_rect or a sphere (or -1)", i);
+    }
+    bool lambert = false;
+    for (int i = 0; i < d->n_materials; ++i) lambert |= d->materials[i].kind == RT_MAT_LAMBERTIAN;
+    if (lambert && d->n_lights < 1)
+        return rt_fail(RT_ERR_INVALID, "rt_scene_create: lambertian surfaces need a non-empty important_hitables list");
+    return RT_OK;
+}
+
+extern "C" int rt_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out)
+{
+    if (!out) return rt_fail(RT_ERR_INVALID, "rt_scene_create: null output");
+    *out = nullptr;
+    int st = validate(d);
+    if (st != RT_OK) return st;
+    int ndev = rt_device_count();
+    if (ndev < 0) return ndev;
+    if (device < 0 || device >= ndev) return rt_fail(RT_ERR_NO_DEVICE, "rt_scene_create: device %d of %d", device, ndev);
+    RT_HIP(hipSetDevice(device));
+
+    // one blob, every table 256-byte aligned
+    struct part {
+        const void *src;
+        size_t bytes, off;
+    };
+    part parts[8] = {
+        {d->entries, sizeof(rt_entry) * (size_t)d->n_entries, 0},
+        {d->prims, sizeof(rt_prim) * (size_t)d->n_prims, 0},
+        {d->xforms, sizeof(rt_xform) * (size_t)d->n_xforms, 0},
+        {d->chains, sizeof(rt_chain) * (size_t)d->n_chains, 0},
+        {d->materials, sizeof(rt_material) * (size_t)d->n_materials, 0},
+        {d->textures, sizeof(rt_texture) * (size_t)d->n_textures, 0},
+        {d->texels, (size_t)d->n_texel_bytes, 0},
+        {d->lights, sizeof(int32_t) * (size_t)d->n_lights, 0},
+    };
+    size_t total = 0;
+    for (part &p : parts) {
+        p.off = total;
+        total += (p.bytes + 255) & ~(size_t)255;
+        total += 256; // a table may be empty; keep pointers distinct and in bounds
+    }
+    std::vector<uint8_t> staging(total, 0);
+    for (part &p : parts)
+        if (p.bytes) memcpy(staging.data() + p.off, p.src, p.bytes);
+
+    rt_scene *s = new (std::nothrow) rt_scene;
+    if (!s) return rt_fail(RT_ERR_NOMEM, "rt_scene_create: out of host memory");
+    s->device = device;
+    hipError_t e = hipMalloc(&s->blob, total);
+    if (e != hipSuccess) {
+        delete s;
+        return rt_fail(RT_ERR_NOMEM, "hipMalloc(%zu): %s", total, hipGetErrorString(e));
+    }
+    e = hipMemcpy(s->blob, staging.data(), total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e != hipSuccess) {
+        rt_fail(RT_ERR_NO_DEVICE, "rt_scene_create: %s", hipGetErrorString(e));
+        rt_scene_destroy(s);
+        return RT_ERR_NO_DEVICE;
+    }
+    uint8_t *b = (uint8_t *)s->blob;
+    DevScene &D = s->dev;
+    D.entries = (const rt_entry *)(b + parts[0].off);
+    D.prims = (const rt_prim *)(b + parts[1].off);
+    D.xforms = (const rt_xform *)(b + parts[2].off);
+    D.chains = (const rt_chain *)(b + parts[3].off);
+    D.materials = (const rt_material *)(b + parts[4].off);
+    D.textures = (const rt_texture *)(b + parts[5].off);
+    D.texels = (const uint8_t *)(b + parts[6].off);
+    D.lights = (const int32_t *)(b + parts[7].off);
+    D.n_entries = d->n_entries, D.n_lights = d->n_lights;
+    D.cam = d->camera;
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->blob) (void)hipFree(s->blob);
+    delete s;
+}
+
+static int check_params(const rt_render_params *p, const char *who)
+{
+    if (!p || p->struct_size != sizeof(rt_render_params)) return rt_fail(RT_ERR_INVALID, "%s: bad rt_render_params", who);
+    if (p->nx < 1 || p->ny < 1 || p->nx > 65536 || p->ny > 65536) return rt_fail(RT_ERR_INVALID, "%s: image size %dx%d", who, p->nx, p->ny);
+    if (p->sample_begin < 0 || p->sample_end < p->sample_begin) return rt_fail(RT_ERR_INVALID, "%s: sample range [%d,%d)", who, p->sample_begin, p->sample_end);
+    if (p->sub_samples < 1 || p->sub_samples > 4096) return rt_fail(RT_ERR_INVALID, "%s: sub_samples %d", who, p->sub_samples);
+    if (p->max_depth < 0) return rt_fail(RT_ERR_INVALID, "%s: max_depth %d", who, p->max_depth);
+    if ((int64_t)(p->sample_end - p->sample_begin) * p->sub_samples > (1 << 24))
+        return rt_fail(RT_ERR_INVALID, "%s: more than 2^24 paths per pixel in one call; split the sample range", who);
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum, void *stream_)
+{
+    if (!s || !d_accum) return rt_fail(RT_ERR_INVALID, "rt_render: null argument");
+    int st = check_params(p, "rt_render");
+    if (st != RT_OK) return st;
+    hipStream_t stream = (hipStream_t)stream_;
+    RT_HIP(hipSetDevice(s->device));
+    const size_t bytes = sizeof(float) * 4 * (size_t)p->nx * p->ny;
+    const bool accumulate = (p->flags & RT_RENDER_ACCUMULATE) != 0;
+    const int ns = p->sample_end - p->sample_begin;
+    if (ns == 0) {
+        if (!accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
+        return RT_OK;
+    }
+    RenderArgs A;
+    A.nx = p->nx, A.ny = p->ny;
+    A.tiles_x = (p->nx + 7) / 8, A.tiles_y = (p->ny + 7) / 8;
+    const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
+    // Enough tasks to fill 256 CUs several times over, but each with at least 16 paths
+    // per lane so that the fill/drain of a task's pool stays small beside its body.
+    int64_t want_chunks = (32768 + tiles - 1) / tiles;
+    int64_t max_chunks = ((int64_t)ns * p->sub_samples + 15) / 16;
+    if (want_chunks > max_chunks) want_chunks = max_chunks;
+    if (want_chunks > ns) want_chunks = ns;
+    if (want_chunks < 1) want_chunks = 1;
+    A.chunk_samples = (int)((ns + want_chunks - 1) / want_chunks);
+    A.n_chunks = (ns + A.chunk_samples - 1) / A.chunk_samples;
+    A.sample_begin = p->sample_begin, A.n_samples = ns;
+    A.sub_samples = p->sub_samples, A.max_depth = p->max_depth, A.seed = p->seed;
+    A.atomic_out = (accumulate || A.n_chunks > 1) ? 1 : 0;
+    const int64_t n_tasks = tiles * A.n_chunks;
+    if (n_tasks > 0x7fffffff / 8) return rt_fail(RT_ERR_INVALID, "rt_render: %lld tasks; split the call", (long long)n_tasks);
+    A.n_tasks = (int)n_tasks;
+    if (A.atomic_out && !accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
+    const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    RT_HIP(hipEventRecord(s->ev0, stream));
+    hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(s->ev1, stream));
+    s->timed = true;
+    return RT_OK;
+}
+
+extern "C" int rt_last_render_ms(rt_scene *s, float *ms)
+{
+    if (!s || !ms) return rt_fail(RT_ERR_INVALID, "rt_last_render_ms: null argument");
+    if (!s->timed) return rt_fail(RT_ERR_INVALID, "rt_last_render_ms: no render has been recorded on this scene");
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipEventSynchronize(s->ev1));
+    RT_HIP(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return RT_OK;
+}
+
+extern "C" int rt_resolve(const float *d_accum, int32_t nx, int32_t ny, uint32_t *d_rgba8, void *stream_)
+{
+    if (!d_accum || !d_rgba8 || nx < 1 || ny < 1) return rt_fail(RT_ERR_INVALID, "rt_resolve: bad argument");
+    const int n = nx * ny;
+    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, (const float4 *)d_accum, n, d_rgba8);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_render_to_host(rt_scene *s, const rt_render_params *p, float *h_accum, uint32_t *h_rgba8)
+{
+    if (!s || !h_accum) return rt_fail(RT_ERR_INVALID, "rt_render_to_host: null argument");
+    int st = check_params(p, "rt_render_to_host");
+    if (st != RT_OK) return st;
+    RT_HIP(hipSetDevice(s->device));
+    const size_t n = (size_t)p->nx * p->ny;
+    float *d_accum = nullptr;
+    uint32_t *d_img = nullptr;
+    RT_HIP(hipMalloc(&d_accum, n * 16));
+    hipError_t e = h_rgba8 ? hipMalloc(&d_img, n * 4) : hipSuccess;
+    if (e == hipSuccess) {
+        rt_render_params q = *p;
+        q.flags &= ~RT_RENDER_ACCUMULATE;
+        st = rt_render(s, &q, d_accum, nullptr);
+        if (st == RT_OK && h_rgba8) st = rt_resolve(d_accum, p->nx, p->ny, d_img, nullptr);
+        if (st == RT_OK) e = hipMemcpy(h_accum, d_accum, n * 16, hipMemcpyDeviceToHost);
+        if (st == RT_OK && e == hipSuccess && h_rgba8) e = hipMemcpy(h_rgba8, d_img, n * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_accum);
+    if (d_img) (void)hipFree(d_img);
+    if (e != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "rt_render_to_host: %s", hipGetErrorString(e));
+    return st;
+}
+
+extern "C" int rt_camera_rays(rt_scene *s, int32_t n, const float *h_st, const float *h_lens, const float *h_time01, float *h_rays)
+{
+    if (!s || n < 0 || (n > 0 && (!h_st || !h_rays))) return rt_fail(RT_ERR_INVALID, "rt_camera_rays: bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(s->device));
+    float *d = nullptr; // st | lens | time | rays
+    const size_t N = (size_t)n;
+    RT_HIP(hipMalloc(&d, sizeof(float) * N * (2 + 2 + 1 + 7)));
+    float *d_st = d, *d_lens = d + 2 * N, *d_time = d + 4 * N, *d_rays = d + 5 * N;
+    hipError_t e = hipMemcpy(d_st, h_st, 8 * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess && h_lens) e = hipMemcpy(d_lens, h_lens, 8 * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess && h_time01) e = hipMemcpy(d_time, h_time01, 4 * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(camera_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev.cam, n, d_st, h_lens ? d_lens : nullptr,
+                           h_time01 ? d_time : nullptr, d_rays);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_rays, d_rays, 28 * N, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "rt_camera_rays: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float t_min, float t_max, uint32_t seed, rt_hit *h_hits)
+{
+    if (!s || n < 0 || (n > 0 && (!h_rays || !h_hits))) return rt_fail(RT_ERR_INVALID, "rt_trace_rays: bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(s->device));
+    const size_t N = (size_t)n;
+    float *d_rays = nullptr;
+    rt_hit *d_hits = nullptr;
+    RT_HIP(hipMalloc(&d_rays, 28 * N));
+    hipError_t e = hipMalloc(&d_hits, sizeof(rt_hit) * N);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, h_rays, 28 * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_hits, d_hits, sizeof(rt_hit) * N, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    if (d_hits) (void)hipFree(d_hits);
+    if (e != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "rt_trace_rays: %s", hipGetErrorString(e));
+    return RT_OK;
+}

@@ -1,0 +1,156 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ray_tracing_amd import api
+from ray_tracing_amd.api import HostScene, Scene
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def gpu_render(scene, nx, ny, s0, s1, **kw):
+    import torch
+    acc = torch.empty((ny, nx, 4), dtype=torch.float32, device="cuda:0")
+    api.render(scene, acc, nx, ny, s0, s1, **kw)
+    torch.cuda.synchronize()
+    return acc.cpu().numpy()
+
+
+@pytest.mark.parametrize("key,nx,ny", [("hits_128x128", 128, 128), ("hits_200x120", 200, 120)])
+def test_primary_hits_bit_exact_vs_reference(golden, key, nx, ny):
+    """north_star check 1: primary-ray closest-hit primitive ids (and t, p, normal) bit-exact
+    with the reference's hitable::hit on the same camera."""
+    tab = golden[key].reshape(-1, 20)
+    hs = HostScene("cornell_box", nx / ny)
+    sc = Scene(hs, 0)
+    rays = api.camera_rays(sc, tab[:, 0:2])
+    assert np.array_equal(bits(rays[:, :6]), bits(tab[:, 2:8]))
+    rays[:, 6] = tab[:, 8]
+    hits = api.trace_rays(sc, rays)
+    assert np.array_equal(hits["prim_id"], tab[:, 10].astype(np.int32))
+    m = tab[:, 9] > 0.5
+    assert np.array_equal(bits(hits["t"][m]), bits(tab[m, 11]))
+    assert np.array_equal(bits(hits["p"][m]), bits(tab[m, 14:17]))
+    assert np.array_equal(bits(hits["normal"][m]), bits(tab[m, 17:20]))
+    sc.close()
+
+
+def test_secondary_rays_bit_exact_vs_oracle(cornell_host, cornell_gpu):
+    """Incoherent rays from inside the box (what bounces look like), every lane on its own course."""
+    rng = np.random.default_rng(5)
+    n = 50000
+    o = rng.uniform(1, 554, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[::7, 0] = 0.0  # axis-parallel directions: 1/d = inf in the slab test
+    d[::11, 1] = -0.0
+    rays = np.concatenate([o, d, np.zeros((n, 1), np.float32)], axis=1)
+    for (tmin, tmax) in [(0.001, O.FLT_MAX), (0.001, 300.0)]:
+        g = api.trace_rays(cornell_gpu, rays, tmin, tmax)
+        c = O.trace_rays(cornell_host, rays, tmin, tmax)
+        assert np.array_equal(g["prim_id"], c["prim_id"])
+        assert np.array_equal(g["material"], c["material"])
+        m = c["prim_id"] >= 0
+        assert np.array_equal(bits(g["t"][m]), bits(c["t"][m]))
+        assert np.array_equal(bits(g["p"][m]), bits(c["p"][m]))
+        assert np.array_equal(bits(g["normal"][m]), bits(c["normal"][m]))
+
+
+def test_trace_edge_cases(cornell_gpu, cornell_host):
+    assert len(api.trace_rays(cornell_gpu, np.zeros((0, 7), np.float32))) == 0
+    one = np.array([[278, 278, -800, 0, 0, 1, 0]], dtype=np.float32)
+    g, c = api.trace_rays(cornell_gpu, one), O.trace_rays(cornell_host, one)
+    assert g["prim_id"][0] == c["prim_id"][0] >= 0 and bits(g["t"])[0] == bits(c["t"])[0]
+    # a ragged count (not a multiple of the wave or block size)
+    rays = np.tile(one, (1000 + 37, 1))
+    assert np.all(api.trace_rays(cornell_gpu, rays)["prim_id"] == c["prim_id"][0])
+    away = np.array([[278, 278, -800, 0, 0, -1, 0]], dtype=np.float32)
+    assert api.trace_rays(cornell_gpu, away)["prim_id"][0] == -1
+
+
+@pytest.mark.parametrize("nx,ny,ns,nss,depth", [(64, 64, 8, 1, 50), (40, 24, 4, 2, 5), (33, 17, 3, 1, 1), (16, 16, 2, 1, 0)])
+def test_render_matches_oracle_on_the_same_stream(nx, ny, ns, nss, depth):
+    """Same scene, same per-path random stream (include/rt_rng.h), same draw order: the GPU image must
+    equal the CPU oracle's pixel by pixel up to libm/rounding differences.  A path can diverge when an
+    ulp flips a comparison, so a small fraction of pixels may differ by more; none may differ in the mean.
+    Tolerance: >= 97 % of pixels within 1e-3 relative (+1e-4 absolute), image mean within 1 %."""
+    hs = HostScene("cornell_box", nx / ny)
+    sc = Scene(hs, 0)
+    g = gpu_render(sc, nx, ny, 0, ns, sub_samples=nss, max_depth=depth, seed=3)
+    c, _, _ = O.render(hs, nx, ny, 0, ns, nss, depth, O.ORC_RNG_COUNTER, 3, 8)
+    assert np.all(g[..., 0] == ns) and np.all(c[..., 0] == ns)
+    close = np.isclose(g[..., 1:], c[..., 1:], rtol=1e-3, atol=1e-4).all(axis=-1)
+    assert close.mean() >= 0.97, f"only {close.mean():.4f} of pixels agree"
+    gm, cm = g[..., 1:].mean(axis=(0, 1)), c[..., 1:].mean(axis=(0, 1))
+    assert np.allclose(gm, cm, rtol=1e-2, atol=1e-5), (gm, cm)
+    sc.close()
+
+
+def test_render_is_deterministic_and_sample_ranges_add_up(cornell_gpu):
+    """Disjoint sample ranges (what different GPUs render) sum to the full render: the paths are
+    keyed by (pixel, sample), not by who traces them.  Float sums differ only in order."""
+    import torch
+    nx = ny = 48
+    full = gpu_render(cornell_gpu, nx, ny, 0, 16, seed=11)
+    again = gpu_render(cornell_gpu, nx, ny, 0, 16, seed=11)
+    assert np.allclose(full, again, rtol=1e-5, atol=1e-6)
+    acc = torch.zeros((ny, nx, 4), dtype=torch.float32, device="cuda:0")
+    for (a, b) in [(0, 5), (5, 6), (6, 16)]:
+        api.render(cornell_gpu, acc, nx, ny, a, b, seed=11, accumulate=True)
+    torch.cuda.synchronize()
+    parts = acc.cpu().numpy()
+    assert np.all(parts[..., 0] == 16)
+    assert np.allclose(full, parts, rtol=1e-4, atol=1e-5)
+    other = gpu_render(cornell_gpu, nx, ny, 0, 16, seed=12)
+    assert not np.allclose(full, other, rtol=1e-3)
+    empty = gpu_render(cornell_gpu, nx, ny, 4, 4, seed=11)
+    assert not empty.any()
+
+
+def test_resolve_matches_oracle(cornell_gpu):
+    import torch
+    nx, ny = 40, 24
+    acc = torch.empty((ny, nx, 4), dtype=torch.float32, device="cuda:0")
+    api.render(cornell_gpu, acc, nx, ny, 0, 8, seed=1)
+    img = api.resolve(acc)
+    torch.cuda.synchronize()
+    want = O.resolve(acc.cpu().numpy())
+    assert np.array_equal(img.cpu().numpy().view(np.uint32), want)
+    # special values: a NaN/inf/negative accumulator must quantise like the CPU loop does
+    a = torch.tensor([[[4.0, 0.0, 2.0, 8.0], [1.0, float("inf"), -1.0, 0.25]]], device="cuda:0")
+    assert np.array_equal(api.resolve(a).cpu().numpy().view(np.uint32), O.resolve(a.cpu().numpy()))
+
+
+def test_statistical_parity_with_reference_image():
+    """north_star check 2 at test scale: per-channel image mean within 3 standard errors of the
+    reference's converged render, PSNR of the 8-bit images stated.  The reference image is the
+    4096-spp golden fixture when present (256x256, -t 1)."""
+    path = os.path.join(O.GOLD, "cornell_box_256x256_4096spp_r50.npy")
+    if not os.path.exists(path):
+        pytest.skip("converged reference fixture not generated yet")
+    ref = np.load(path)  # (ny, nx, 3) RGB means
+    ny, nx = ref.shape[:2]
+    hs = HostScene("cornell_box", nx / ny)
+    sc = Scene(hs, 0)
+    batches = [gpu_render(sc, nx, ny, k * 512, (k + 1) * 512, seed=21)[..., 1:][..., ::-1] / 512.0 for k in range(8)]
+    sc.close()
+    gpu = np.mean(batches, axis=0)  # 4096 spp, RGB
+    gmean = np.array([b.mean(axis=(0, 1)) for b in batches])  # (8, 3) image means per batch
+    se_gpu = gmean.std(axis=0, ddof=1) / np.sqrt(len(batches))
+    # the reference render has the same per-sample variance at equal spp
+    se = np.sqrt(2.0) * se_gpu
+    diff = np.abs(gpu.mean(axis=(0, 1)) - ref.mean(axis=(0, 1)))
+    assert np.all(diff <= 3.0 * se + 1e-6), (diff, se)
+
+    def to8(x):
+        return np.floor(np.clip(np.sqrt(np.maximum(x, 0)), 0, 1) * 255.99)
+    mse = np.mean((to8(gpu) - to8(ref)) ** 2)
+    psnr = 10 * np.log10(255.0 ** 2 / mse)
+    print(f"PSNR gpu(4096 spp) vs reference(4096 spp) = {psnr:.2f} dB; mean diff {diff}, 3*SE {3 * se}")
+    assert psnr >= 30.0

@@ -1,0 +1,207 @@
+"""Pins the CPU oracle (oracle/rt_oracle.cpp) and the host flattener to the REAL reference.
+
+Every expected value in tests/golden/ was written by the reference's own code
+(oracle/ref_harness_tail.cpp appended to /root/reference/src/main.cpp; see
+oracle/make_golden.py).  Comparisons are on float BITS unless stated.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ray_tracing_amd import _capi
+from ray_tracing_amd.api import HostScene
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def fp(a):
+    return np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_samples_bit_identical_square(golden, cornell_host):
+    ref = golden["samples_64x64_s4_S1_r50"]
+    total, per_sample, _ = O.render(cornell_host, 64, 64, 0, 4, 1, 50, O.ORC_RNG_MINSTD, cornell_host.ran01_state, 1, True)
+    assert np.array_equal(bits(per_sample), bits(ref))
+    # the sum the resolve loop forms (src/main.cpp:720-726): float adds in sample order
+    acc = np.zeros_like(ref[0])
+    for s in range(4):
+        acc = acc + ref[s]
+    assert np.array_equal(bits(total), bits(acc))
+
+
+def test_samples_bit_identical_subsamples_aspect(golden):
+    ref = golden["samples_48x32_s2_S2_r5"]
+    hs = HostScene("cornell_box", 48 / 32)
+    _, per_sample, _ = O.render(hs, 48, 32, 0, 2, 2, 5, O.ORC_RNG_MINSTD, hs.ran01_state, 1, True)
+    assert np.array_equal(bits(per_sample), bits(ref))
+
+
+@pytest.mark.parametrize("key,nx,ny", [("hits_128x128", 128, 128), ("hits_200x120", 200, 120)])
+def test_primary_hits_match_reference(golden, key, nx, ny):
+    tab = golden[key].reshape(-1, 20)
+    hs = HostScene("cornell_box", nx / ny)
+    rays = O.camera_rays(hs, tab[:, 0:2])
+    assert np.array_equal(bits(rays[:, :6]), bits(tab[:, 2:8]))  # origin, direction (aperture 0: no randomness)
+    rays[:, 6] = tab[:, 8]  # the shutter time the reference drew
+    hits = O.trace_rays(hs, rays)
+    hit_ref = tab[:, 9] > 0.5
+    assert np.array_equal(hits["prim_id"] >= 0, hit_ref)
+    assert np.array_equal(hits["prim_id"], tab[:, 10].astype(np.int32))
+    m = hit_ref
+    assert np.array_equal(bits(hits["t"][m]), bits(tab[m, 11]))
+    assert np.array_equal(bits(hits["p"][m]), bits(tab[m, 14:17]))
+    assert np.array_equal(bits(hits["normal"][m]), bits(tab[m, 17:20]))
+    assert m.sum() > 0.5 * len(m) and len(np.unique(hits["prim_id"])) >= 8  # the table exercises the whole scene
+
+
+def test_flattened_tree_matches_reference_dump(cornell_host):
+    """Same tree shape, same boxes (hex floats), same leaf order as the reference's bvh_node."""
+    def hexfloats(line):
+        return [float.fromhex(x.strip("[]")) for x in line.split() if x.strip("[]").startswith(("0x", "-0x"))]
+
+    lines = open(os.path.join(O.GOLD, "cornell_box_tree.txt")).read().splitlines()
+    want_boxes = [hexfloats(l) for l in lines if l.split()[0] == "bvh"]
+    want_leaves = [(l.split()[0], int(l.split()[2])) for l in lines
+                   if l.split()[0] in ("sphere", "xy_rect", "xz_rect", "yz_rect", "moving_sphere", "medium")]
+    d = cornell_host.desc.contents
+    got_boxes, got_leaves = [], []
+    names = {_capi.RT_PRIM_SPHERE: "sphere", _capi.RT_PRIM_XY_RECT: "xy_rect", _capi.RT_PRIM_XZ_RECT: "xz_rect",
+             _capi.RT_PRIM_YZ_RECT: "yz_rect", _capi.RT_PRIM_MOVING_SPHERE: "moving_sphere", _capi.RT_PRIM_MEDIUM: "medium"}
+    for i in range(d.n_entries):
+        e = d.entries[i]
+        if (e.b & 255) == _capi.RT_ENTRY_INNER:
+            got_boxes.append(list(e.lo) + list(e.hi))
+            assert i < e.a <= d.n_entries
+        else:
+            p = d.prims[e.a]
+            if p.kind == _capi.RT_PRIM_GROUP:
+                for k in range(p.count):
+                    c = d.prims[p.first + k]
+                    got_leaves.append((names[c.kind], c.user_id))
+            else:
+                got_leaves.append((names[p.kind], p.user_id))
+    assert got_leaves == want_leaves
+    assert np.array_equal(bits(np.array(got_boxes)), bits(np.array(want_boxes)))
+    # camera frame, bit for bit
+    vals = hexfloats([l for l in lines if l.startswith("camera")][0])
+    c = d.camera
+    got = list(c.origin) + list(c.lower_left_corner) + list(c.horizontal) + list(c.vertical) + [c.lens_radius, c.time0, c.time1]
+    assert np.array_equal(bits(np.array(got)), bits(np.array(vals)))
+
+
+# ---- per-function known answers ------------------------------------------------
+def test_kat_aabb(kat):
+    lib = O.load()
+    for r in kat["kat_aabb_hit"]:
+        got = lib.orc_kat_aabb_hit(fp(r[0:3]), fp(r[3:6]), fp(r[6:9]), fp(r[9:12]), float(r[12]), float(r[13]))
+        assert got == int(r[14])
+
+
+def test_kat_sphere(kat):
+    lib = O.load()
+    out = np.zeros(9, dtype=np.float32)
+    n_hit = 0
+    for r in kat["kat_sphere_hit"]:
+        got = lib.orc_kat_sphere_hit(fp(r[0:3]), fp(r[3:6]), fp(r[6:9]), float(r[9]), float(r[10]), float(r[11]), fp(out))
+        assert got == int(r[12])
+        if got:
+            n_hit += 1
+            assert np.array_equal(bits(out), bits(r[13:22]))
+    assert n_hit > 100
+
+
+def test_kat_rect(kat):
+    lib = O.load()
+    out = np.zeros(9, dtype=np.float32)
+    n_hit = 0
+    for r in kat["kat_rect_hit"]:
+        got = lib.orc_kat_rect_hit(int(r[0]), fp(r[1:4]), fp(r[4:7]), fp(r[7:12]), float(r[12]), float(r[13]), fp(out))
+        assert got == int(r[14])
+        if got:
+            n_hit += 1
+            assert np.array_equal(bits(out), bits(r[15:24]))
+    assert n_hit > 30
+
+
+def test_kat_optics(kat):
+    lib = O.load()
+    out = np.zeros(8, dtype=np.float32)
+    for r in kat["kat_optics"]:
+        lib.orc_kat_optics(fp(r[0:3]), fp(r[3:6]), float(r[6]), float(r[7]), float(r[8]), fp(out))
+        assert np.array_equal(bits(out), bits(r[9:17]))
+
+
+def test_kat_onb_and_sphere_uv(kat):
+    lib = O.load()
+    out = np.zeros(14, dtype=np.float32)
+    for r in kat["kat_onb_uv"]:
+        lib.orc_kat_onb_uv(fp(r[0:3]), fp(out))
+        assert np.array_equal(bits(out), bits(r[3:17]))
+
+
+def test_kat_pdf_values(kat):
+    lib = O.load()
+    nz = 0
+    for r in kat["kat_pdf"]:
+        got = np.float32(lib.orc_kat_pdf_value(int(r[0]), fp(r[1:4]), fp(r[4:7]), fp(r[7:12])))
+        assert bits(got) == bits(r[12])
+        nz += got > 0
+        cv = np.float32(lib.orc_kat_cosine_pdf_value(fp(r[13:16]), fp(r[4:7])))
+        assert bits(cv) == bits(r[16])
+    assert nz > 100
+
+
+def test_kat_perlin(kat):
+    lib = O.load()
+    for r in kat["kat_perlin"]:
+        assert bits(np.float32(lib.orc_kat_perlin_noise(fp(r[0:3])))) == bits(r[3])
+        assert bits(np.float32(lib.orc_kat_perlin_turb(fp(r[0:3])))) == bits(r[4])
+
+
+def _texture_desc(textures, texels=None):
+    d = _capi.rt_scene_desc()
+    arr = (_capi.rt_texture * len(textures))(*textures)
+    d.textures, d.n_textures = arr, len(textures)
+    keep = [arr]
+    if texels is not None:
+        buf = (C.c_uint8 * len(texels)).from_buffer_copy(texels.tobytes())
+        d.texels, d.n_texel_bytes = buf, len(texels)
+        keep.append(buf)
+    return d, keep
+
+
+def test_kat_textures(kat):
+    lib = O.load()
+    W, H = 7, 5
+    px = ((np.arange(W * H * 3) * 37 + 11) & 255).astype(np.uint8)  # the harness's synthetic image
+    T = _capi.rt_texture
+    tex = [T(_capi.RT_TEX_IMAGE, -1, -1, W, H, 0, 0, (C.c_float * 3)(0, 0, 0), 0.0),
+           T(_capi.RT_TEX_CONSTANT, -1, -1, 0, 0, 0, 0, (C.c_float * 3)(0, 0, 0), 0.0),
+           T(_capi.RT_TEX_CONSTANT, -1, -1, 0, 0, 0, 0, (C.c_float * 3)(1, 1, 1), 0.0),
+           T(_capi.RT_TEX_CHECKER, 1, 2, 0, 0, 0, 0, (C.c_float * 3)(0, 0, 0), 0.0),
+           T(_capi.RT_TEX_NOISE, -1, -1, 0, 0, 0, 0, (C.c_float * 3)(0, 0, 0), 0.1),
+           T(_capi.RT_TEX_NOISE, -1, -1, 0, 0, 0, 0, (C.c_float * 3)(0, 0, 0), 2.0)]
+    d, keep = _texture_desc(tex, px)
+    rgb = np.zeros(3, dtype=np.float32)
+    zero = np.zeros(3, dtype=np.float32)
+    for r in kat["kat_textures"]:
+        lib.orc_kat_texture(C.byref(d), 0, float(r[0]), float(r[1]), fp(zero), fp(rgb))
+        assert np.array_equal(bits(rgb), bits(r[2:5]))
+        lib.orc_kat_texture(C.byref(d), 3, 0.0, 0.0, fp(r[5:8]), fp(rgb))
+        assert rgb[0] == r[8]
+    for r in kat["kat_perlin"]:
+        lib.orc_kat_texture(C.byref(d), 4 if r[5] < 1.0 else 5, 0.0, 0.0, fp(r[0:3]), fp(rgb))
+        assert bits(rgb[0]) == bits(r[6])
+
+
+def test_counter_mode_is_thread_count_invariant(cornell_host):
+    a, _, _ = O.render(cornell_host, 24, 24, 0, 3, 1, 50, O.ORC_RNG_COUNTER, 7, 1)
+    b, _, _ = O.render(cornell_host, 24, 24, 0, 3, 1, 50, O.ORC_RNG_COUNTER, 7, 4)
+    assert np.array_equal(bits(a), bits(b))
+    c, _, _ = O.render(cornell_host, 24, 24, 0, 3, 1, 50, O.ORC_RNG_COUNTER, 8, 4)
+    assert not np.array_equal(bits(a), bits(c))
