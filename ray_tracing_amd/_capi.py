@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librt_amd.so")
+# RT_AMD_LIB selects another build of the same library (kernel experiments); the default is the in-tree one
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "librt_amd.so")
 
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM = -1, -2, -3, -4

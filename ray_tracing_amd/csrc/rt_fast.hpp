@@ -1,0 +1,411 @@
+// rt_fast.hpp -- the render path for scenes that fit the register-resident record
+// table (rt_records.h): same algorithm and same random-draw order as rt_device.hpp,
+// different machine mapping.
+//
+//   * The scene is 8 VGPRs: lane L holds record L.  The scan reads record i (a
+//     wave-uniform index) with v_readlane: scene data reaches the VALU as SGPR
+//     operands without a memory access, so the inner loop has no load latency at all.
+//   * During the scan a lane keeps only (t, record index) of its closest hit.  The
+//     hit point, normal and material are built once per ray afterwards: the lane
+//     fetches the winning record and its material record with ds_bpermute.
+//   * Spheres are stored in world space (a rigid chain is folded into the centre),
+//     rect records carry their world normal, p = o + t*d is evaluated on the world
+//     ray: instance chains cost nothing outside the boxes and rects under them.
+//   * Arithmetic is hardware-rate: v_rcp/v_sqrt/v_rsq/v_sin/v_cos/v_log (about 1 ulp)
+//     and FMA contraction, 1/d hoisted per ray.  Results therefore differ from the
+//     reference in the last bits; the bit-exact path (rt_device.hpp) remains the one
+//     that rt_trace_rays uses by default, and tests/test_gpu_parity.py compares the
+//     two paths with each other, with the oracle on the same random stream, and
+//     with the reference's converged image.
+//   * Comparisons are written in their positive form (t >= t_min && t <= t_max ...)
+//     so that a NaN never counts as a hit; the reference's negative forms accept a
+//     NaN t, which only arises for a ray origin exactly on a primitive's plane with a
+//     direction exactly parallel to it.
+#ifndef RT_FAST_HPP_
+#define RT_FAST_HPP_
+
+#include "rt_device.hpp"
+#include "rt_records.h"
+
+namespace rtf {
+
+using rt::DevScene;
+using rt::Ray;
+using rt::Rng;
+using rt::V3;
+using rt::v3;
+
+#define RTF_DEV __device__ __forceinline__
+#pragma clang fp contract(fast)
+
+RTF_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RTF_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+RTF_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+RTF_DEV float fmin3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+RTF_DEV float fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+RTF_DEV V3 fma3(float t, V3 d, V3 o) { return v3(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z)); }
+RTF_DEV float fdot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+RTF_DEV V3 funit(V3 a)
+{
+    float k = rsq(fdot(a, a));
+    return v3(a.x * k, a.y * k, a.z * k);
+}
+RTF_DEV V3 fcross(V3 a, V3 b)
+{
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// sin and cos of 2*RT_PI*r (RT_PI = 3.14159f, src/main.cpp:54): the hardware takes revolutions
+RTF_DEV void sincos_2pi(float r, float &s, float &c)
+{
+    const float rev = r * (RT_PI / 3.14159265358979323846f);
+    s = __builtin_amdgcn_sinf(rev);
+    c = __builtin_amdgcn_cosf(rev);
+}
+
+struct Regs { // the record table, one record per lane
+    uint32_t d[8];
+};
+RTF_DEV float rl_f(uint32_t v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(v, lane)); }
+RTF_DEV uint32_t rl_u(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+RTF_DEV uint32_t sh_u(uint32_t v, int lane) { return (uint32_t)__shfl((int)v, lane, 64); }
+RTF_DEV float sh_f(uint32_t v, int lane) { return __uint_as_float(sh_u(v, lane)); }
+
+struct Layout { // wave-uniform description of the table
+    int32_t n_stream, materials_base, lights_base, n_lights;
+};
+
+// the ray in the space of the current chain, with what the slab and rect tests need
+struct LocalRay {
+    V3 o, d, inv;
+};
+RTF_DEV void set_local(LocalRay &l, V3 o, V3 d)
+{
+    l.o = o, l.d = d;
+    l.inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
+}
+
+// translate::hit / rotate_y::hit on the way down (src/transforms.h:17, 107-110), operations from records
+RTF_DEV void apply_chain(const Regs &R, uint32_t chain_bits, const Ray &wr, LocalRay &l)
+{
+    V3 o = wr.o, d = wr.d;
+    const int first = chain_bits & 63, count = chain_bits >> 6;
+    for (int k = 0; k < count; ++k) {
+        const uint32_t kind = rl_u(R.d[7], first + k) & 15u;
+        const float a = rl_f(R.d[0], first + k), b = rl_f(R.d[1], first + k);
+        if (kind == RT_REC_XFORM_T) {
+            const float c = rl_f(R.d[2], first + k);
+            o = v3(o.x - a, o.y - b, o.z - c);
+        } else { // a = sin, b = cos
+            const float ox = b * o.x - a * o.z, oz = a * o.x + b * o.z;
+            const float dx = b * d.x - a * d.z, dz = a * d.x + b * d.z;
+            o.x = ox, o.z = oz, d.x = dx, d.z = dz;
+        }
+    }
+    set_local(l, o, d);
+}
+
+// ---------------------------------------------------------------------------
+// world->hit(): bvh_node::hit (src/bvh.h:123-163) over the record stream.
+// Returns the closest t and the stream index of the record that was hit (-1: miss).
+// Lists (box faces) follow hitable_list::hit (src/hitable_list.h:18-34): the upper
+// bound shrinks from member to member, then the list's result competes like any leaf:
+// it replaces the best so far unless the best is strictly nearer (src/bvh.h:132-139).
+// ---------------------------------------------------------------------------
+RTF_DEV void scan(const Regs &R, const Layout &Y, const Ray &wr, float t_min, float t_max, bool alive, float &best_t,
+                  int &best_rec)
+{
+    best_t = __builtin_inff();
+    best_rec = -1;
+    int resume = 0;
+    uint32_t cur_chain = 0;
+    LocalRay w, l; // world ray, ray of the current chain
+    set_local(w, wr.o, wr.d);
+    l = w;
+    const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
+    float gt = t_max; // bound and winner inside the current list
+    int grec = -1;
+
+    for (int i = 0; i < Y.n_stream;) {
+        const uint32_t kw = rl_u(R.d[7], i);
+        const uint32_t kind = kw & 15u;
+        const bool on = alive && resume <= i;
+        if (kind != RT_REC_SPHERE) {
+            const uint32_t chain = (kw >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK;
+            if (chain != cur_chain) {
+                if (chain == 0) l = w;
+                else apply_chain(R, chain, wr, l);
+                cur_chain = chain;
+            }
+        }
+        if (kind == RT_REC_INNER) { // aabb::hit, src/aabb.h:60-83
+            const float x0 = (rl_f(R.d[0], i) - l.o.x) * l.inv.x, x1 = (rl_f(R.d[4], i) - l.o.x) * l.inv.x;
+            const float y0 = (rl_f(R.d[1], i) - l.o.y) * l.inv.y, y1 = (rl_f(R.d[5], i) - l.o.y) * l.inv.y;
+            const float z0 = (rl_f(R.d[2], i) - l.o.z) * l.inv.z, z1 = (rl_f(R.d[6], i) - l.o.z) * l.inv.z;
+            const float tn = fmaxf(fmax3(fminf(x0, x1), fminf(y0, y1), fminf(z0, z1)), t_min);
+            const float tf = fminf(fmin3(fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1)), t_max);
+            const bool in = tf > tn;
+            const int skip = (int)rl_u(R.d[3], i);
+            if (on && !in) resume = skip;
+            i = __any(on && in) ? i + 1 : skip;
+            continue;
+        }
+        if (kw & RT_KW_FIRST) gt = t_max, grec = -1;
+        if (kind == RT_REC_RECT) { // src/plane.h:9-29, 47-67, 109-129
+            const uint32_t axis = (kw >> RT_KW_AXIS_SHIFT) & 3u;
+            float ok, ik, oa, da, ob, db;
+            if (axis == 0) ok = l.o.z, ik = l.inv.z, oa = l.o.x, da = l.d.x, ob = l.o.y, db = l.d.y;
+            else if (axis == 1) ok = l.o.y, ik = l.inv.y, oa = l.o.x, da = l.d.x, ob = l.o.z, db = l.d.z;
+            else ok = l.o.x, ik = l.inv.x, oa = l.o.y, da = l.d.y, ob = l.o.z, db = l.d.z;
+            const float t = (rl_f(R.d[4], i) - ok) * ik;
+            const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
+            const bool in = on && t >= t_min && t <= gt && a >= rl_f(R.d[0], i) && a <= rl_f(R.d[1], i) &&
+                            b >= rl_f(R.d[2], i) && b <= rl_f(R.d[3], i);
+            gt = in ? t : gt;
+            grec = in ? i : grec;
+        } else { // sphere, world space: src/sphere.h:21-59
+            const V3 oc = v3(wr.o.x - rl_f(R.d[0], i), wr.o.y - rl_f(R.d[1], i), wr.o.z - rl_f(R.d[2], i));
+            const float radius = rl_f(R.d[3], i);
+            const float b = fdot(oc, wr.d);
+            const float c = fmaf(-radius, radius, fdot(oc, oc));
+            const float disc = fmaf(b, b, -(w_dd * c));
+            const float sq = fsqrt(disc);
+            const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
+            const bool in1 = t1 < gt && t1 > t_min, in2 = t2 < gt && t2 > t_min;
+            const bool in = on && disc > 0.0f && (in1 || in2);
+            gt = in ? (in1 ? t1 : t2) : gt;
+            grec = in ? i : grec;
+        }
+        if (kw & RT_KW_LAST) {
+            const bool take = grec >= 0 && gt <= best_t;
+            best_t = take ? gt : best_t;
+            best_rec = take ? grec : best_rec;
+        }
+        ++i;
+    }
+}
+
+// what shading needs about the hit, built after the scan from the winning record
+struct Surface {
+    V3 p, n;
+    uint32_t mat_kind;
+    int32_t texture;
+    float p0;
+    V3 color;
+};
+RTF_DEV void build_surface(const Regs &R, const Layout &Y, const Ray &wr, float t, int rec, Surface &s)
+{
+    const int src = rec < 0 ? 0 : rec;
+    const uint32_t kw = sh_u(R.d[7], src);
+    const float f0 = sh_f(R.d[0], src), f1 = sh_f(R.d[1], src), f2 = sh_f(R.d[2], src);
+    const float f4 = sh_f(R.d[4], src), f5 = sh_f(R.d[5], src), f6 = sh_f(R.d[6], src);
+    s.p = fma3(t, wr.d, wr.o);
+    if ((kw & 15u) == RT_REC_SPHERE) {
+        const float k = (kw & RT_KW_FLIP) ? -f4 : f4; // (p - c) / r, src/sphere.h:41, then flip_normals
+        s.n = v3((s.p.x - f0) * k, (s.p.y - f1) * k, (s.p.z - f2) * k);
+    } else {
+        const bool xz = ((kw >> RT_KW_AXIS_SHIFT) & 3u) == 1u;
+        s.n = v3(f5, xz ? ((kw & RT_KW_FLIP) ? -1.0f : 1.0f) : 0.0f, f6);
+    }
+    const int m = Y.materials_base + (int)((kw >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK);
+    s.mat_kind = sh_u(R.d[0], m);
+    s.texture = (int32_t)sh_u(R.d[1], m);
+    s.p0 = sh_f(R.d[2], m);
+    s.color = v3(sh_f(R.d[3], m), sh_f(R.d[4], m), sh_f(R.d[5], m));
+}
+
+// ---------------------------------------------------------------------------
+// sampling (draw order as oracle/rt_oracle.cpp)
+// ---------------------------------------------------------------------------
+RTF_DEV V3 random_in_unit_sphere(Rng &rng) // src/utils.h:32-42
+{
+    V3 p;
+    do {
+        const float c = rng.next(), b = rng.next(), a = rng.next();
+        p = v3(2.0f * a - 1.0f, 2.0f * b - 1.0f, 2.0f * c - 1.0f);
+    } while (fdot(p, p) >= 1.0f);
+    return p;
+}
+RTF_DEV V3 random_in_unit_disk(Rng &rng) // src/utils.h:44-55
+{
+    V3 p;
+    do {
+        const float b = rng.next(), a = rng.next();
+        p = v3(2.0f * a - 1.0f, 2.0f * b - 1.0f, 0.0f);
+    } while (fdot(p, p) >= 1.0f);
+    return p;
+}
+struct Onb {
+    V3 u, v, w;
+    RTF_DEV void build_from_w(V3 n) // src/vec3.h:209-224
+    {
+        w = funit(n);
+        const V3 a = fabsf(w.x) > 0.9f ? v3(0, 1, 0) : v3(1, 0, 0);
+        v = funit(fcross(w, a));
+        u = fcross(w, v);
+    }
+    RTF_DEV V3 local(V3 a) const
+    {
+        return v3(fmaf(a.z, w.x, fmaf(a.y, v.x, a.x * u.x)), fmaf(a.z, w.y, fmaf(a.y, v.y, a.x * u.y)),
+                  fmaf(a.z, w.z, fmaf(a.y, v.z, a.x * u.z)));
+    }
+};
+
+// hitable_list::pdf_value over the light records, src/hitable_list.h:67-77
+RTF_DEV float lights_pdf_value(const Regs &R, const Layout &Y, V3 o, V3 v)
+{
+    const float weight = rcp((float)Y.n_lights);
+    const float vv = fdot(v, v);
+    float sum = 0.0f;
+    for (int k = 0; k < Y.n_lights; ++k) {
+        const int i = Y.lights_base + k;
+        const uint32_t kind = rl_u(R.d[7], i) & 15u;
+        float pdf = 0.0f;
+        if (kind == RT_REC_LIGHT_RECT) { // xz_rect::pdf_value, src/plane.h:76-91
+            const float t = (rl_f(R.d[4], i) - o.y) * rcp(v.y);
+            const float x = fmaf(t, v.x, o.x), z = fmaf(t, v.z, o.z);
+            const bool in = t >= 0.0001f && x >= rl_f(R.d[0], i) && x <= rl_f(R.d[1], i) && z >= rl_f(R.d[2], i) &&
+                            z <= rl_f(R.d[3], i);
+            const float cosine = fabsf(v.y) * rsq(vv);
+            pdf = in ? t * t * vv * rcp(cosine * rl_f(R.d[5], i)) : 0.0f;
+        } else if (kind == RT_REC_LIGHT_SPHERE) { // sphere::pdf_value, src/sphere.h:68-83
+            const V3 oc = v3(o.x - rl_f(R.d[0], i), o.y - rl_f(R.d[1], i), o.z - rl_f(R.d[2], i));
+            const float radius = rl_f(R.d[3], i);
+            const float b = fdot(oc, v), occ = fdot(oc, oc);
+            const float c = fmaf(-radius, radius, occ);
+            const float disc = fmaf(b, b, -(vv * c));
+            const float sq = fsqrt(disc), ia = rcp(vv);
+            const float t1 = (-b - sq) * ia, t2 = (-b + sq) * ia;
+            const bool in = disc > 0.0f && (t1 > 0.001f || t2 > 0.001f);
+            const float cos_theta_max = fsqrt(1.0f - radius * radius * rcp(occ));
+            pdf = in ? rcp(2.0f * RT_PI * (1.0f - cos_theta_max)) : 0.0f;
+        }
+        sum = fmaf(weight, pdf, sum);
+    }
+    return sum;
+}
+// hitable_list::random, src/hitable_list.h:79-88: the member is chosen per lane
+RTF_DEV V3 lights_random(const Regs &R, const Layout &Y, V3 o, Rng &rng)
+{
+    int index = (int)(rng.next() * (float)Y.n_lights);
+    if (index == Y.n_lights) index--;
+    const int i = Y.lights_base + index;
+    const uint32_t kind = sh_u(R.d[7], i) & 15u;
+    const float f0 = sh_f(R.d[0], i), f1 = sh_f(R.d[1], i), f2 = sh_f(R.d[2], i), f3 = sh_f(R.d[3], i), f4 = sh_f(R.d[4], i);
+    if (kind == RT_REC_LIGHT_RECT) { // xz_rect::random, src/plane.h:94-98 (z takes the first draw)
+        const float rz = rng.next(), rx = rng.next();
+        return v3(fmaf(rx, f1 - f0, f0) - o.x, f4 - o.y, fmaf(rz, f3 - f2, f2) - o.z);
+    }
+    if (kind == RT_REC_LIGHT_SPHERE) { // sphere::random + random_to_sphere, src/sphere.h:85-103
+        const V3 direction = v3(f0 - o.x, f1 - o.y, f2 - o.z);
+        const float distance_squared = fdot(direction, direction);
+        Onb uvw;
+        uvw.build_from_w(direction);
+        const float r1 = rng.next();
+        const float r2 = rng.next();
+        const float z = fmaf(r2, fsqrt(1.0f - f3 * f3 * rcp(distance_squared)) - 1.0f, 1.0f);
+        float s, c;
+        sincos_2pi(r1, s, c);
+        const float q = fsqrt(1.0f - z * z);
+        return uvw.local(v3(c * q, s * q, z));
+    }
+    return v3(1, 0, 0); // hitable::random, src/hitable.h:20
+}
+
+// One bounce of color() (src/main.cpp:91-127) in throughput form; see rt::shade for the derivation.
+RTF_DEV bool shade(const DevScene &S, const Regs &R, const Layout &Y, bool hit_any, const Surface &h, Ray &r, V3 &T,
+                   int &depth, int max_depth, Rng &rng, V3 &L)
+{
+    L = v3(0, 0, 0);
+    if (!hit_any) return false;
+    V3 albedo = h.color;
+    if (h.texture >= 0) albedo = rt::tex_value(S, h.texture, 0.0f, 0.0f, h.p); // noise / checker: memory path
+    if (h.mat_kind == RT_MAT_DIFFUSE_LIGHT) {
+        L = v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
+        return false;
+    }
+    if (!(depth < max_depth)) return false;
+    ++depth;
+    if (h.mat_kind == RT_MAT_LAMBERTIAN) {
+        Onb uvw;
+        uvw.build_from_w(h.n);
+        V3 dir;
+        if (rng.next() < 0.5f) {
+            dir = funit(lights_random(R, Y, h.p, rng));
+        } else { // cosine_pdf::generate with random_cosine_direction's factor 2 (src/vec3.h:179-180)
+            const float r1 = rng.next();
+            const float r2 = rng.next();
+            float s, c;
+            sincos_2pi(r1, s, c);
+            const float q = 2.0f * fsqrt(r2);
+            dir = funit(uvw.local(v3(c * q, s * q, fsqrt(1.0f - r2))));
+        }
+        const float cosine = fdot(dir, uvw.w);
+        const float cos_val = cosine > 0.0f ? cosine * (1.0f / RT_PI) : 0.0f;
+        const float pdf_val = 0.5f * lights_pdf_value(R, Y, h.p, dir) + 0.5f * cos_val;
+        const float sc = fmaxf(fdot(h.n, dir), 0.0f) * (1.0f / RT_PI);
+        const float wgt = sc * rcp(pdf_val);
+        T = v3(T.x * albedo.x * wgt, T.y * albedo.y * wgt, T.z * albedo.z * wgt);
+        r = Ray{h.p, dir, r.time};
+        // 0/0 is the NaN the reference's de_nan zeroes; a zero weight is final
+        return wgt == wgt && (T.x != 0.0f || T.y != 0.0f || T.z != 0.0f);
+    }
+    if (h.mat_kind == RT_MAT_METAL) { // src/material.h:65-78
+        const V3 ud = funit(r.d);
+        const float k = 2.0f * fdot(ud, h.n);
+        const V3 fz = random_in_unit_sphere(rng);
+        T = v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
+        r = Ray{h.p, v3(fmaf(h.p0, fz.x, ud.x - k * h.n.x), fmaf(h.p0, fz.y, ud.y - k * h.n.y), fmaf(h.p0, fz.z, ud.z - k * h.n.z)),
+                r.time};
+        return true;
+    }
+    if (h.mat_kind == RT_MAT_DIELECTRIC) { // src/material.h:92-145
+        const float inv_len = rsq(fdot(r.d, r.d));
+        const V3 ud = v3(r.d.x * inv_len, r.d.y * inv_len, r.d.z * inv_len);
+        const float dn = fdot(r.d, h.n);
+        const bool inside = dn > 0.0f;
+        const float ref_idx = h.p0;
+        const float ni_over_nt = inside ? ref_idx : rcp(ref_idx);
+        const V3 on = inside ? v3(-h.n.x, -h.n.y, -h.n.z) : h.n;
+        const float cosine = (inside ? ref_idx * dn : -dn) * inv_len;
+        const float dt = fdot(ud, on);
+        const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+        float reflect_prob = 1.0f;
+        if (disc > 0.0f) { // schlick, src/utils.h:4-9
+            float r0 = (1.0f - ref_idx) * rcp(1.0f + ref_idx);
+            r0 = r0 * r0;
+            const float x = 1.0f - cosine, x2 = x * x;
+            reflect_prob = fmaf(1.0f - r0, x2 * x2 * x, r0);
+        }
+        V3 out;
+        if (rng.next() < reflect_prob) {
+            const float k = 2.0f * fdot(ud, h.n);
+            out = v3(ud.x - k * h.n.x, ud.y - k * h.n.y, ud.z - k * h.n.z);
+        } else { // refract, src/utils.h:16-30
+            const float sq = fsqrt(disc);
+            out = v3(ni_over_nt * (ud.x - on.x * dt) - on.x * sq, ni_over_nt * (ud.y - on.y * dt) - on.y * sq,
+                     ni_over_nt * (ud.z - on.z * dt) - on.z * sq);
+        }
+        r = Ray{h.p, out, r.time};
+        return true;
+    }
+    // isotropic, src/material.h:187-196
+    const V3 dir = random_in_unit_sphere(rng);
+    T = v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
+    r = Ray{h.p, dir, 0.0f};
+    return true;
+}
+
+// camera::get_ray, src/camera.h:54-68
+RTF_DEV Ray camera_ray(const rt_camera &c, float s, float t, V3 disk, float time01)
+{
+    const float rx = c.lens_radius * disk.x, ry = c.lens_radius * disk.y;
+    const V3 oo = v3(fmaf(c.v[0], ry, fmaf(c.u[0], rx, c.origin[0])), fmaf(c.v[1], ry, fmaf(c.u[1], rx, c.origin[1])),
+                     fmaf(c.v[2], ry, fmaf(c.u[2], rx, c.origin[2])));
+    const V3 d = v3(fmaf(t, c.vertical[0], fmaf(s, c.horizontal[0], c.lower_left_corner[0])) - oo.x,
+                    fmaf(t, c.vertical[1], fmaf(s, c.horizontal[1], c.lower_left_corner[1])) - oo.y,
+                    fmaf(t, c.vertical[2], fmaf(s, c.horizontal[2], c.lower_left_corner[2])) - oo.z);
+    return Ray{oo, d, fmaf(time01, c.time1 - c.time0, c.time0)};
+}
+
+} // namespace rtf
+#endif // RT_FAST_HPP_

@@ -1,0 +1,201 @@
+// rt_records.cpp -- builds the register-resident record table (rt_records.h) from a scene description.
+#include "rt_records.h"
+
+#include <cstring>
+#include <map>
+#include <vector>
+
+namespace {
+
+uint32_t fbits(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+bool plain_static(int kind) { return kind == RT_PRIM_SPHERE || (kind >= RT_PRIM_XY_RECT && kind <= RT_PRIM_YZ_RECT); }
+
+// the way back up an instance chain (innermost wrapper first), src/transforms.h:21, 114-122
+void chain_up_point(const rt_scene_desc *d, int chain, float p[3])
+{
+    const rt_chain &c = d->chains[chain];
+    for (int i = c.count - 1; i >= 0; --i) {
+        const rt_xform &x = d->xforms[c.first + i];
+        if (x.kind == RT_XFORM_TRANSLATE) {
+            p[0] += x.a, p[1] += x.b, p[2] += x.c;
+        } else {
+            float s = x.a, co = x.b, px = p[0], pz = p[2];
+            p[0] = co * px + s * pz;
+            p[2] = -s * px + co * pz;
+        }
+    }
+}
+void chain_up_normal(const rt_scene_desc *d, int chain, float n[3])
+{
+    const rt_chain &c = d->chains[chain];
+    for (int i = c.count - 1; i >= 0; --i) {
+        const rt_xform &x = d->xforms[c.first + i];
+        if (x.kind == RT_XFORM_ROTATE_Y) {
+            float s = x.a, co = x.b, nx = n[0], nz = n[2];
+            n[0] = co * nx + s * nz;
+            n[2] = -s * nx + co * nz;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, const char **why)
+{
+    static const char *ok = "";
+    *why = ok;
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < RT_REC_MAX; ++i) out->user_id[i] = out->prim[i] = -1;
+
+    // ---- does the scene qualify, and how many records does it need? ----------------
+    std::vector<int> map(d->n_entries + 1, 0); // entry index -> stream index
+    std::map<int, int> chain_first;            // chain id -> first record of its operations
+    int n_stream = 0;
+    std::vector<int> chains_used;
+    auto use_chain = [&](int c) {
+        if (c != 0 && !chain_first.count(c)) {
+            chain_first[c] = -1;
+            chains_used.push_back(c);
+        }
+    };
+    for (int e = 0; e < d->n_entries; ++e) {
+        map[e] = n_stream;
+        const rt_entry &en = d->entries[e];
+        if ((en.b & 255) == RT_ENTRY_INNER) {
+            use_chain(en.b >> 8);
+            ++n_stream;
+            continue;
+        }
+        const rt_prim &p = d->prims[en.a];
+        if (p.kind == RT_PRIM_GROUP) {
+            for (int k = 0; k < p.count; ++k) {
+                const rt_prim &c = d->prims[p.first + k];
+                if (!plain_static(c.kind)) { *why = "a list member is not a static sphere or rect"; return 0; }
+                if (c.flags & RT_PRIM_NEEDS_UV) { *why = "a texture reads (u,v)"; return 0; }
+                if (c.kind != RT_PRIM_SPHERE) use_chain(p.chain);
+            }
+            n_stream += p.count;
+        } else if (plain_static(p.kind)) {
+            if (p.flags & RT_PRIM_NEEDS_UV) { *why = "a texture reads (u,v)"; return 0; }
+            if (p.kind != RT_PRIM_SPHERE) use_chain(p.chain);
+            ++n_stream;
+        } else {
+            *why = "scene has a constant_medium or a moving_sphere";
+            return 0;
+        }
+    }
+    map[d->n_entries] = n_stream;
+    int n_chain_recs = 0;
+    for (int c : chains_used) {
+        if (d->chains[c].count > 7) { *why = "an instance chain is longer than 7"; return 0; }
+        n_chain_recs += d->chains[c].count;
+    }
+    if (d->n_materials > 255) { *why = "more than 255 materials"; return 0; }
+    int total = n_stream + n_chain_recs + d->n_materials + d->n_lights;
+    if (total > RT_REC_MAX) { *why = "more than 64 records"; return 0; }
+
+    // ---- lay out: stream | chain operations | materials | lights ---------------------
+    int at = n_stream;
+    for (int c : chains_used) {
+        chain_first[c] = at;
+        for (int k = 0; k < d->chains[c].count; ++k, ++at) {
+            const rt_xform &x = d->xforms[d->chains[c].first + k];
+            uint32_t *r = out->rec[at];
+            r[0] = fbits(x.a), r[1] = fbits(x.b), r[2] = fbits(x.c);
+            r[7] = x.kind == RT_XFORM_TRANSLATE ? RT_REC_XFORM_T : RT_REC_XFORM_R;
+        }
+    }
+    auto chain_word = [&](int c) -> uint32_t {
+        if (c == 0) return 0;
+        return ((uint32_t)chain_first[c] | ((uint32_t)d->chains[c].count << 6)) << RT_KW_CHAIN_SHIFT;
+    };
+    out->materials_base = at;
+    for (int m = 0; m < d->n_materials; ++m, ++at) {
+        const rt_material &mt = d->materials[m];
+        uint32_t *r = out->rec[at];
+        r[0] = (uint32_t)mt.kind;
+        r[2] = fbits(mt.p0);
+        int tex = mt.texture;
+        if (tex >= 0 && d->textures[tex].kind == RT_TEX_CONSTANT) {
+            r[1] = (uint32_t)-1;
+            for (int k = 0; k < 3; ++k) r[3 + k] = fbits(d->textures[tex].color[k]);
+        } else {
+            r[1] = (uint32_t)tex; // -1 for dielectric
+            for (int k = 0; k < 3; ++k) r[3 + k] = fbits(1.0f);
+        }
+        r[7] = RT_REC_MATERIAL;
+    }
+    out->lights_base = at;
+    out->n_lights = d->n_lights;
+    for (int l = 0; l < d->n_lights; ++l, ++at) {
+        uint32_t *r = out->rec[at];
+        int pi = d->lights[l];
+        if (pi < 0) {
+            r[7] = RT_REC_LIGHT_NONE;
+            continue;
+        }
+        const rt_prim &p = d->prims[pi];
+        for (int k = 0; k < 5; ++k) r[k] = fbits(p.f[k]);
+        if (p.kind == RT_PRIM_XZ_RECT) {
+            r[5] = fbits((p.f[1] - p.f[0]) * (p.f[3] - p.f[2])); // area, src/plane.h:82
+            r[7] = RT_REC_LIGHT_RECT;
+        } else {
+            r[7] = RT_REC_LIGHT_SPHERE;
+        }
+    }
+    out->n_records = at;
+    out->n_stream = n_stream;
+
+    // ---- the traversal stream ------------------------------------------------------------
+    auto emit_prim = [&](int s, int prim_index, const rt_prim &p, int chain, uint32_t list_bits) {
+        uint32_t *r = out->rec[s];
+        uint32_t kw = list_bits | ((uint32_t)p.material << RT_KW_MAT_SHIFT);
+        if (p.flags & RT_PRIM_FLIP) kw |= RT_KW_FLIP;
+        if (p.kind == RT_PRIM_SPHERE) {
+            float c[3] = {p.f[0], p.f[1], p.f[2]};
+            chain_up_point(d, chain, c);
+            for (int k = 0; k < 3; ++k) r[k] = fbits(c[k]);
+            r[3] = fbits(p.f[3]);
+            r[4] = fbits(1.0f / p.f[3]);
+            kw |= RT_REC_SPHERE;
+        } else {
+            for (int k = 0; k < 5; ++k) r[k] = fbits(p.f[k]);
+            int axis = p.kind == RT_PRIM_XY_RECT ? 0 : p.kind == RT_PRIM_XZ_RECT ? 1 : 2;
+            float n[3] = {axis == 2 ? 1.0f : 0.0f, axis == 1 ? 1.0f : 0.0f, axis == 0 ? 1.0f : 0.0f};
+            if (p.flags & RT_PRIM_FLIP)
+                for (float &x : n) x = -x;
+            chain_up_normal(d, chain, n);
+            r[5] = fbits(n[0]), r[6] = fbits(n[2]);
+            kw |= RT_REC_RECT | ((uint32_t)axis << RT_KW_AXIS_SHIFT) | chain_word(chain);
+        }
+        r[7] = kw;
+        out->user_id[s] = p.user_id;
+        out->prim[s] = prim_index;
+    };
+    for (int e = 0; e < d->n_entries; ++e) {
+        const rt_entry &en = d->entries[e];
+        int s = map[e];
+        if ((en.b & 255) == RT_ENTRY_INNER) {
+            uint32_t *r = out->rec[s];
+            for (int k = 0; k < 3; ++k) r[k] = fbits(en.lo[k]), r[4 + k] = fbits(en.hi[k]);
+            r[3] = (uint32_t)map[en.a];
+            r[7] = RT_REC_INNER | chain_word(en.b >> 8);
+            continue;
+        }
+        const rt_prim &p = d->prims[en.a];
+        if (p.kind == RT_PRIM_GROUP) {
+            for (int k = 0; k < p.count; ++k)
+                emit_prim(s + k, p.first + k, d->prims[p.first + k], p.chain,
+                          (k == 0 ? RT_KW_FIRST : 0u) | (k == p.count - 1 ? RT_KW_LAST : 0u));
+        } else {
+            emit_prim(s, en.a, p, p.chain, RT_KW_FIRST | RT_KW_LAST);
+        }
+    }
+    return 1;
+}

@@ -1,0 +1,74 @@
+// rt_records.h -- the register-resident form of a small scene.
+//
+// A scene of at most 64 records is kept, for the whole life of a wave, in eight
+// VGPRs: lane L holds the eight dwords of record L.  The wave-uniform scan then
+// fetches record i with v_readlane (VGPR -> SGPR, no memory access, no latency to
+// hide), and a lane fetches "its" record (the primitive it hit, its material, the
+// light it sampled) with ds_bpermute.  The Cornell box needs 33 records.
+//
+// Record kinds and dword layout (d0..d6 are floats unless noted, d7 is the kind word):
+//   INNER     d0-2 box min, d3 (int) stream index to continue at when the box is missed, d4-6 box max
+//   RECT      d0 a0, d1 a1, d2 b0, d3 b1, d4 k, d5 world normal x, d6 world normal z
+//             (world normal y is +-1 for an xz rect and 0 otherwise: chains are y-rotations and shifts)
+//   SPHERE    d0-2 centre IN WORLD SPACE (a rigid chain is folded in), d3 radius, d4 1/radius
+//   XFORM_T   d0-2 offset                     (src/transforms.h:14-28)
+//   XFORM_R   d0 sin_theta, d1 cos_theta      (src/transforms.h:102-130)
+//   MATERIAL  d0 (int) rt_material_kind, d1 (int) texture index or -1 when the colour is inline,
+//             d2 p0 (fuzz / ref_idx), d3-5 constant colour
+//   LIGHT     d0-4 as RECT (xz) or d0-3 as SPHERE, d5 rect area
+// kind word:  bits 0-3 kind | 4-5 rect axis (0 xy, 1 xz, 2 yz) | 6 flip | 7 first of its list | 8 last of its list
+//             | 9-14 first record of the instance chain | 15-17 number of chain records
+//             | 18-25 material record (relative to materials_base)
+#ifndef RT_RECORDS_H_
+#define RT_RECORDS_H_
+
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+
+#define RT_REC_MAX 64
+
+enum rt_rec_kind {
+    RT_REC_INNER = 0,
+    RT_REC_RECT = 1,
+    RT_REC_SPHERE = 2,
+    RT_REC_XFORM_T = 3,
+    RT_REC_XFORM_R = 4,
+    RT_REC_MATERIAL = 5,
+    RT_REC_LIGHT_RECT = 6,
+    RT_REC_LIGHT_SPHERE = 7,
+    RT_REC_LIGHT_NONE = 8
+};
+
+#define RT_KW_AXIS_SHIFT 4
+#define RT_KW_FLIP (1u << 6)
+#define RT_KW_FIRST (1u << 7)
+#define RT_KW_LAST (1u << 8)
+#define RT_KW_CHAIN_SHIFT 9   /* 9 bits: first record (6) | count (3) << 6 */
+#define RT_KW_CHAIN_MASK 0x1ffu
+#define RT_KW_MAT_SHIFT 18
+#define RT_KW_MAT_MASK 0xffu
+
+typedef struct rt_record_table {
+    uint32_t rec[RT_REC_MAX][8];
+    int32_t user_id[RT_REC_MAX]; /* rt_prim.user_id of primitive records (for rt_trace_rays) */
+    int32_t prim[RT_REC_MAX];    /* rt_prim index of primitive records */
+    int32_t n_stream;            /* records [0, n_stream) are the traversal stream */
+    int32_t materials_base;
+    int32_t lights_base, n_lights;
+    int32_t n_records;
+} rt_record_table;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Builds the table from a validated description.  Returns 1 if the scene fits
+ * (<= 64 records, only spheres / rects / boxes / flat lists, no media, no moving
+ * spheres, no texture that needs (u,v)), 0 if it does not (the caller then uses
+ * the generic memory-resident path).  `why` receives a short reason. */
+int rt_records_build(const rt_scene_desc *d, rt_record_table *out, const char **why);
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_RECORDS_H_ */
