@@ -234,6 +234,25 @@ int rt_trace_rays(rt_scene* scene, int32_t n, const float* h_rays, float t_min, 
                   uint32_t seed, rt_hit* h_hits_out);
 
 /* ------------------------------------------------------------------ */
+/* Execution paths                                                      */
+/* ------------------------------------------------------------------ */
+/* The library holds two device implementations of world->hit() + color():
+ *   RT_PATH_EXACT  scene tables in memory, read through wave-uniform scalar loads;
+ *                  any scene the flattener accepts; every float operation that
+ *                  decides a hit repeats the reference's, so ids, t, p and normal
+ *                  equal the CPU reference bit for bit.
+ *   RT_PATH_FAST   scenes of at most 64 records (the Cornell box: 33) held in
+ *                  registers, hardware-rate reciprocal/sqrt and FMA; same algorithm,
+ *                  same random-draw order, results equal up to rounding.
+ * RT_PATH_AUTO (default): rt_render uses FAST when the scene fits, else EXACT;
+ * rt_trace_rays uses EXACT.  No counterpart in the reference (it has one CPU path). */
+enum rt_option { RT_OPT_RENDER_PATH = 1, RT_OPT_TRACE_PATH = 2 };
+enum rt_path { RT_PATH_AUTO = 0, RT_PATH_EXACT = 1, RT_PATH_FAST = 2 };
+int rt_scene_set_option(rt_scene* scene, int option, int value);
+enum rt_info { RT_INFO_FAST_PATH_AVAILABLE = 1, RT_INFO_LAST_RENDER_PATH = 2, RT_INFO_RECORDS = 3 };
+int rt_scene_get_info(rt_scene* scene, int what, int* value);
+
+/* ------------------------------------------------------------------ */
 /* Misc                                                                 */
 /* ------------------------------------------------------------------ */
 const char* rt_last_error(void);

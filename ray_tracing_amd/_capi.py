@@ -15,6 +15,9 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "librt_amd.so")
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM = -1, -2, -3, -4
 RT_RENDER_ACCUMULATE = 1
+RT_OPT_RENDER_PATH, RT_OPT_TRACE_PATH = 1, 2
+RT_PATH_AUTO, RT_PATH_EXACT, RT_PATH_FAST = 0, 1, 2
+RT_INFO_FAST_PATH_AVAILABLE, RT_INFO_LAST_RENDER_PATH, RT_INFO_RECORDS = 1, 2, 3
 
 # enum values (include/rt_amd.h)
 RT_ENTRY_INNER, RT_ENTRY_LEAF = 0, 1
@@ -100,6 +103,8 @@ PROTOTYPES = {
     "rt_abi_version": (C.c_int, []),
     "rt_device_count": (C.c_int, []),
     "rt_last_render_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rt_scene_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rt_scene_get_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     # include/rt_host.h
     "rt_host_scene_build": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
     "rt_host_scene_desc": (C.POINTER(rt_scene_desc), [C.c_void_p]),

@@ -54,6 +54,19 @@ class Scene:
         self._s = C.c_void_p()
         _check(lib.rt_scene_create(self.host.desc, device, C.byref(self._s)), "rt_scene_create")
 
+    def set_path(self, render=None, trace=None):
+        """rt_scene_set_option: choose RT_PATH_AUTO / RT_PATH_EXACT / RT_PATH_FAST for rt_render / rt_trace_rays."""
+        lib = _capi.load()
+        if render is not None:
+            _check(lib.rt_scene_set_option(self._s, _capi.RT_OPT_RENDER_PATH, render), "rt_scene_set_option")
+        if trace is not None:
+            _check(lib.rt_scene_set_option(self._s, _capi.RT_OPT_TRACE_PATH, trace), "rt_scene_set_option")
+
+    def info(self, what):
+        v = C.c_int()
+        _check(_capi.load().rt_scene_get_info(self._s, what, C.byref(v)), "rt_scene_get_info")
+        return v.value
+
     def last_render_ms(self):
         ms = C.c_float()
         _check(_capi.load().rt_last_render_ms(self._s, C.byref(ms)), "rt_last_render_ms")

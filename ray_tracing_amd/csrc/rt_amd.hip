@@ -29,6 +29,8 @@
 
 #include "rt_device.hpp"
 #include "rt_error.h"
+#include "rt_fast.hpp"
+#include "rt_records.h"
 
 using namespace rt;
 
@@ -190,6 +192,139 @@ __global__ void camera_kernel(rt_camera cam, int n, const float *__restrict__ st
     o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z, o[6] = r.time;
 }
 
+
+// ---------------------------------------------------------------------------
+// The same loop on the register-resident record table (rt_fast.hpp): the render
+// path for scenes of at most 64 records.  Lane L loads record L once; after that
+// the scene is never read from memory again.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_records(const uint32_t *__restrict__ recs, int lane, rtf::Regs &R)
+{
+    const uint4 a = reinterpret_cast<const uint4 *>(recs)[2 * lane], b = reinterpret_cast<const uint4 *>(recs)[2 * lane + 1];
+    R.d[0] = a.x, R.d[1] = a.y, R.d[2] = a.z, R.d[3] = a.w, R.d[4] = b.x, R.d[5] = b.y, R.d[6] = b.z, R.d[7] = b.w;
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevScene S, const uint32_t *__restrict__ recs,
+                                                                            rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
+{
+    __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (task >= A.n_tasks) return;
+    rtf::Regs R;
+    load_records(recs, lane, R);
+
+    const int tile = task / A.n_chunks, chunk = task - tile * A.n_chunks;
+    const int tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
+    const int s0 = chunk * A.chunk_samples;
+    const int s1 = min(s0 + A.chunk_samples, A.n_samples);
+    const int total = 64 * (s1 - s0) * A.sub_samples;
+    const float inv_nx = 1.0f / float(A.nx), inv_ny = 1.0f / float(A.ny);
+
+    float *acc = tile_acc[wave];
+    acc[lane] = 0.0f, acc[64 + lane] = 0.0f, acc[128 + lane] = 0.0f;
+
+    int next = 0;
+    bool alive = false;
+    Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
+    V3 T = v3(1, 1, 1);
+    Rng rng{0u, 0u};
+    int depth = 0, pix = lane;
+
+    for (;;) {
+        const unsigned long long dead = __ballot(!alive);
+        if (dead != 0ull && next < total) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+            const int item = next + rank;
+            if (!alive && item < total) {
+                pix = item & 63;
+                const int q = item >> 6;
+                const int sample = A.sample_begin + s0 + q / A.sub_samples;
+                const int sub = q - (q / A.sub_samples) * A.sub_samples;
+                const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
+                if (col < A.nx && row < A.ny) {
+                    rng.key = rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub));
+                    rng.n = 0;
+                    const int j = A.ny - 1 - row;
+                    const float u = (float(col) + rng.next()) * inv_nx;
+                    const float v = (float(j) + rng.next()) * inv_ny;
+                    const V3 disk = rtf::rnd_unit_disk(rng);
+                    const float time01 = rng.next();
+                    r = rtf::camera_ray(S.cam, u, v, disk, time01);
+                    T = v3(1, 1, 1);
+                    depth = 0;
+                    alive = true;
+                }
+            }
+            next += __popcll(dead);
+        }
+        if (!__any(alive)) {
+            if (next >= total) break;
+            continue;
+        }
+
+        float t;
+        int rec;
+        rtf::scan(R, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
+        rtf::Surface sf;
+        rtf::build_surface(R, Y, r, t, rec, sf); // every lane takes part in the cross-lane fetches
+
+        if (alive) {
+            V3 L;
+            if (!rtf::shade(S, R, Y, rec >= 0, sf, r, T, depth, A.max_depth, rng, L)) {
+                alive = false;
+                if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
+                if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
+                if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[128 + pix], L.z);
+            }
+        }
+    }
+
+    const int col = tile_x * 8 + (lane & 7), row = tile_y * 8 + (lane >> 3);
+    if (col < A.nx && row < A.ny) {
+        const float inv = 1.0f / (float)A.sub_samples;
+        float4 o = make_float4((float)(s1 - s0), acc[128 + lane] * inv, acc[64 + lane] * inv, acc[lane] * inv);
+        float *dst = accum + 4 * ((size_t)row * A.nx + col);
+        if (A.atomic_out) {
+            atomicAdd(dst + 0, o.x), atomicAdd(dst + 1, o.y), atomicAdd(dst + 2, o.z), atomicAdd(dst + 3, o.w);
+        } else {
+            *reinterpret_cast<float4 *>(dst) = o;
+        }
+    }
+}
+
+// world->hit() on the record table (what render_fast_kernel's bounces see)
+__global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restrict__ recs, const int32_t *__restrict__ rec_user,
+                                                         rtf::Layout Y, int n, const float *__restrict__ rays, float t_min,
+                                                         float t_max, rt_hit *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    rtf::Regs R;
+    load_records(recs, lane, R);
+    const bool alive = i < n;
+    const int k = alive ? i : 0;
+    const float *f = rays + 7 * (size_t)k;
+    Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
+    float t;
+    int rec;
+    rtf::scan(R, Y, r, t_min, t_max, alive, t, rec);
+    rtf::Surface sf;
+    rtf::build_surface(R, Y, r, t, rec, sf);
+    const uint32_t kw = rtf::sh_u(R.d[7], rec < 0 ? 0 : rec);
+    if (!alive) return;
+    const bool any = rec >= 0;
+    rt_hit o;
+    o.prim_id = any ? rec_user[rec] : -1;
+    o.material = any ? (int)((kw >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK) : -1;
+    o.t = any ? t : 0.0f, o.u = 0.0f, o.v = 0.0f;
+    o.p[0] = any ? sf.p.x : 0.0f, o.p[1] = any ? sf.p.y : 0.0f, o.p[2] = any ? sf.p.z : 0.0f;
+    o.normal[0] = any ? sf.n.x : 0.0f, o.normal[1] = any ? sf.n.y : 0.0f, o.normal[2] = any ? sf.n.z : 0.0f;
+    o.reserved = 0.0f;
+    out[i] = o;
+}
+
 } // namespace
 
 // ===========================================================================
@@ -199,9 +334,16 @@ struct rt_scene {
     int device = 0;
     void *blob = nullptr; // one allocation holding every table
     DevScene dev;
-    bool needs_uv_any = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // register-resident form (rt_records.h), when the scene fits
+    bool fast_ok = false;
+    const char *fast_why = "";
+    rtf::Layout layout{0, 0, 0, 0};
+    uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids (inside blob)
+    int32_t *d_rec_user = nullptr;
+    int render_path = RT_PATH_AUTO, trace_path = RT_PATH_AUTO;
+    int last_render_path = RT_PATH_EXACT;
 };
 
 #define RT_HIP(call)                                                                                                   \
@@ -317,7 +459,10 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         const void *src;
         size_t bytes, off;
     };
-    part parts[8] = {
+    rt_record_table tab;
+    const char *why = "";
+    const bool fast_ok = rt_records_build(d, &tab, &why) != 0;
+    part parts[10] = {
         {d->entries, sizeof(rt_entry) * (size_t)d->n_entries, 0},
         {d->prims, sizeof(rt_prim) * (size_t)d->n_prims, 0},
         {d->xforms, sizeof(rt_xform) * (size_t)d->n_xforms, 0},
@@ -326,6 +471,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         {d->textures, sizeof(rt_texture) * (size_t)d->n_textures, 0},
         {d->texels, (size_t)d->n_texel_bytes, 0},
         {d->lights, sizeof(int32_t) * (size_t)d->n_lights, 0},
+        {tab.rec, sizeof tab.rec, 0},
+        {tab.user_id, sizeof tab.user_id, 0},
     };
     size_t total = 0;
     for (part &p : parts) {
@@ -365,6 +512,10 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     D.lights = (const int32_t *)(b + parts[7].off);
     D.n_entries = d->n_entries, D.n_lights = d->n_lights;
     D.cam = d->camera;
+    s->fast_ok = fast_ok, s->fast_why = why;
+    s->d_records = (uint32_t *)(b + parts[8].off);
+    s->d_rec_user = (int32_t *)(b + parts[9].off);
+    s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights};
     *out = s;
     return RT_OK;
 }
@@ -397,6 +548,9 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     int st = check_params(p, "rt_render");
     if (st != RT_OK) return st;
     hipStream_t stream = (hipStream_t)stream_;
+    if (s->render_path == RT_PATH_FAST && !s->fast_ok)
+        return rt_fail(RT_ERR_UNSUPPORTED, "rt_render: the register-resident path was requested but the scene does not fit it: %s", s->fast_why);
+    const bool use_fast = s->fast_ok && s->render_path != RT_PATH_EXACT;
     RT_HIP(hipSetDevice(s->device));
     const size_t bytes = sizeof(float) * 4 * (size_t)p->nx * p->ny;
     const bool accumulate = (p->flags & RT_RENDER_ACCUMULATE) != 0;
@@ -427,8 +581,12 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     if (A.atomic_out && !accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
     const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     RT_HIP(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
+    if (use_fast)
+        hipLaunchKernelGGL(render_fast_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    else
+        hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
     RT_HIP(hipGetLastError());
+    s->last_render_path = use_fast ? RT_PATH_FAST : RT_PATH_EXACT;
     RT_HIP(hipEventRecord(s->ev1, stream));
     s->timed = true;
     return RT_OK;
@@ -505,6 +663,8 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
 {
     if (!s || n < 0 || (n > 0 && (!h_rays || !h_hits))) return rt_fail(RT_ERR_INVALID, "rt_trace_rays: bad argument");
     if (n == 0) return RT_OK;
+    if (s->trace_path == RT_PATH_FAST && !s->fast_ok)
+        return rt_fail(RT_ERR_UNSUPPORTED, "rt_trace_rays: the register-resident path was requested but the scene does not fit it: %s", s->fast_why);
     RT_HIP(hipSetDevice(s->device));
     const size_t N = (size_t)n;
     float *d_rays = nullptr;
@@ -513,7 +673,11 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
     hipError_t e = hipMalloc(&d_hits, sizeof(rt_hit) * N);
     if (e == hipSuccess) e = hipMemcpy(d_rays, h_rays, 28 * N, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
+        if (s->trace_path == RT_PATH_FAST)
+            hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
+                               d_rays, t_min, t_max, d_hits);
+        else
+            hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(h_hits, d_hits, sizeof(rt_hit) * N, hipMemcpyDeviceToHost);
@@ -521,4 +685,28 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
     if (d_hits) (void)hipFree(d_hits);
     if (e != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "rt_trace_rays: %s", hipGetErrorString(e));
     return RT_OK;
+}
+
+extern "C" int rt_scene_set_option(rt_scene *s, int option, int value)
+{
+    if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: null scene");
+    if (value != RT_PATH_AUTO && value != RT_PATH_EXACT && value != RT_PATH_FAST)
+        return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: value %d", value);
+    if (value == RT_PATH_FAST && !s->fast_ok)
+        return rt_fail(RT_ERR_UNSUPPORTED, "rt_scene_set_option: the scene does not fit the register-resident path: %s", s->fast_why);
+    if (option == RT_OPT_RENDER_PATH) s->render_path = value;
+    else if (option == RT_OPT_TRACE_PATH) s->trace_path = value;
+    else return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: unknown option %d", option);
+    return RT_OK;
+}
+
+extern "C" int rt_scene_get_info(rt_scene *s, int what, int *value)
+{
+    if (!s || !value) return rt_fail(RT_ERR_INVALID, "rt_scene_get_info: null argument");
+    switch (what) {
+    case RT_INFO_FAST_PATH_AVAILABLE: *value = s->fast_ok ? 1 : 0; return RT_OK;
+    case RT_INFO_LAST_RENDER_PATH: *value = s->last_render_path; return RT_OK;
+    case RT_INFO_RECORDS: *value = s->fast_ok ? s->layout.lights_base + s->layout.n_lights : -1; return RT_OK;
+    }
+    return rt_fail(RT_ERR_INVALID, "rt_scene_get_info: unknown item %d", what);
 }

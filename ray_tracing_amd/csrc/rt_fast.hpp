@@ -216,7 +216,7 @@ RTF_DEV void build_surface(const Regs &R, const Layout &Y, const Ray &wr, float 
 // ---------------------------------------------------------------------------
 // sampling (draw order as oracle/rt_oracle.cpp)
 // ---------------------------------------------------------------------------
-RTF_DEV V3 random_in_unit_sphere(Rng &rng) // src/utils.h:32-42
+RTF_DEV V3 rnd_unit_sphere(Rng &rng) // src/utils.h:32-42
 {
     V3 p;
     do {
@@ -225,7 +225,7 @@ RTF_DEV V3 random_in_unit_sphere(Rng &rng) // src/utils.h:32-42
     } while (fdot(p, p) >= 1.0f);
     return p;
 }
-RTF_DEV V3 random_in_unit_disk(Rng &rng) // src/utils.h:44-55
+RTF_DEV V3 rnd_unit_disk(Rng &rng) // src/utils.h:44-55
 {
     V3 p;
     do {
@@ -288,9 +288,17 @@ RTF_DEV V3 lights_random(const Regs &R, const Layout &Y, V3 o, Rng &rng)
 {
     int index = (int)(rng.next() * (float)Y.n_lights);
     if (index == Y.n_lights) index--;
-    const int i = Y.lights_base + index;
-    const uint32_t kind = sh_u(R.d[7], i) & 15u;
-    const float f0 = sh_f(R.d[0], i), f1 = sh_f(R.d[1], i), f2 = sh_f(R.d[2], i), f3 = sh_f(R.d[3], i), f4 = sh_f(R.d[4], i);
+    // This runs under a divergent branch, where ds_bpermute would return 0 for records held by
+    // inactive lanes; v_readlane ignores EXEC, so walk the (few) lights and keep the chosen one.
+    uint32_t kind = RT_REC_LIGHT_NONE;
+    float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f, f3 = 0.0f, f4 = 0.0f;
+    for (int k = 0; k < Y.n_lights; ++k) {
+        const int i = Y.lights_base + k;
+        const bool mine = index == k;
+        kind = mine ? (rl_u(R.d[7], i) & 15u) : kind;
+        f0 = mine ? rl_f(R.d[0], i) : f0, f1 = mine ? rl_f(R.d[1], i) : f1, f2 = mine ? rl_f(R.d[2], i) : f2;
+        f3 = mine ? rl_f(R.d[3], i) : f3, f4 = mine ? rl_f(R.d[4], i) : f4;
+    }
     if (kind == RT_REC_LIGHT_RECT) { // xz_rect::random, src/plane.h:94-98 (z takes the first draw)
         const float rz = rng.next(), rx = rng.next();
         return v3(fmaf(rx, f1 - f0, f0) - o.x, f4 - o.y, fmaf(rz, f3 - f2, f2) - o.z);
@@ -352,7 +360,7 @@ RTF_DEV bool shade(const DevScene &S, const Regs &R, const Layout &Y, bool hit_a
     if (h.mat_kind == RT_MAT_METAL) { // src/material.h:65-78
         const V3 ud = funit(r.d);
         const float k = 2.0f * fdot(ud, h.n);
-        const V3 fz = random_in_unit_sphere(rng);
+        const V3 fz = rnd_unit_sphere(rng);
         T = v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
         r = Ray{h.p, v3(fmaf(h.p0, fz.x, ud.x - k * h.n.x), fmaf(h.p0, fz.y, ud.y - k * h.n.y), fmaf(h.p0, fz.z, ud.z - k * h.n.z)),
                 r.time};
@@ -389,7 +397,7 @@ RTF_DEV bool shade(const DevScene &S, const Regs &R, const Layout &Y, bool hit_a
         return true;
     }
     // isotropic, src/material.h:187-196
-    const V3 dir = random_in_unit_sphere(rng);
+    const V3 dir = rnd_unit_sphere(rng);
     T = v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
     r = Ray{h.p, dir, 0.0f};
     return true;

@@ -5,8 +5,10 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from ray_tracing_amd import api
+from ray_tracing_amd import _capi, api
 from ray_tracing_amd.api import HostScene, Scene
+
+PATHS = {"exact": _capi.RT_PATH_EXACT, "fast": _capi.RT_PATH_FAST}
 
 pytestmark = pytest.mark.gpu
 
@@ -62,6 +64,49 @@ def test_secondary_rays_bit_exact_vs_oracle(cornell_host, cornell_gpu):
         assert np.array_equal(bits(g["normal"][m]), bits(c["normal"][m]))
 
 
+@pytest.mark.parametrize("key,nx,ny", [("hits_128x128", 128, 128), ("hits_200x120", 200, 120)])
+def test_fast_path_primary_ids_vs_reference(golden, key, nx, ny):
+    """The register-resident path (what rt_render uses on this scene) uses reciprocal-multiply arithmetic, so
+    t differs in the last bits; primitive ids of the reference's primary-hit table must agree except for rays
+    that graze an edge exactly."""
+    tab = golden[key].reshape(-1, 20)
+    hs = HostScene("cornell_box", nx / ny)
+    sc = Scene(hs, 0)
+    assert sc.info(_capi.RT_INFO_FAST_PATH_AVAILABLE) == 1 and 0 < sc.info(_capi.RT_INFO_RECORDS) <= 64
+    sc.set_path(trace=_capi.RT_PATH_FAST)
+    rays = tab[:, 2:9].copy()
+    hits = api.trace_rays(sc, rays)
+    same = hits["prim_id"] == tab[:, 10].astype(np.int32)
+    # Pixel-centre rays on the image diagonal run exactly through the box's bottom corners; there one ulp
+    # in t decides between the wall and a miss.  Everything else must agree.  (The EXACT path agrees on all.)
+    assert (~same).sum() <= 4, f"{(~same).sum()} ids differ from the reference"
+    m = (tab[:, 9] > 0.5) & same
+    assert np.allclose(hits["t"][m], tab[m, 11], rtol=1e-4, atol=0)  # sphere roots cancel: -b - sqrt(disc)
+    assert np.allclose(hits["p"][m], tab[m, 14:17], rtol=1e-4, atol=5e-2)
+    assert np.allclose(hits["normal"][m], tab[m, 17:20], atol=1e-3)
+    sc.close()
+
+
+def test_fast_path_agrees_with_exact_path_on_incoherent_rays(cornell_host):
+    rng = np.random.default_rng(9)
+    n = 100000
+    o = rng.uniform(1, 554, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays = np.concatenate([o, d, np.zeros((n, 1), np.float32)], axis=1)
+    sc = Scene(cornell_host, 0)
+    exact = api.trace_rays(sc, rays)
+    sc.set_path(trace=_capi.RT_PATH_FAST)
+    fast = api.trace_rays(sc, rays)
+    sc.close()
+    same = exact["prim_id"] == fast["prim_id"]
+    # an ulp of difference can move a hit across an edge or swap two equal-distance primitives
+    assert same.mean() >= 0.9999, f"{(~same).sum()} of {n} ids differ"
+    m = same & (exact["prim_id"] >= 0)
+    assert np.allclose(fast["t"][m], exact["t"][m], rtol=1e-3, atol=1e-3)
+    assert np.array_equal(fast["material"][m], exact["material"][m])
+    assert np.allclose(fast["normal"][m], exact["normal"][m], atol=1e-3)
+
+
 def test_trace_edge_cases(cornell_gpu, cornell_host):
     assert len(api.trace_rays(cornell_gpu, np.zeros((0, 7), np.float32))) == 0
     one = np.array([[278, 278, -800, 0, 0, 1, 0]], dtype=np.float32)
@@ -74,15 +119,18 @@ def test_trace_edge_cases(cornell_gpu, cornell_host):
     assert api.trace_rays(cornell_gpu, away)["prim_id"][0] == -1
 
 
+@pytest.mark.parametrize("path", ["exact", "fast"])
 @pytest.mark.parametrize("nx,ny,ns,nss,depth", [(64, 64, 8, 1, 50), (40, 24, 4, 2, 5), (33, 17, 3, 1, 1), (16, 16, 2, 1, 0)])
-def test_render_matches_oracle_on_the_same_stream(nx, ny, ns, nss, depth):
+def test_render_matches_oracle_on_the_same_stream(nx, ny, ns, nss, depth, path):
     """Same scene, same per-path random stream (include/rt_rng.h), same draw order: the GPU image must
     equal the CPU oracle's pixel by pixel up to libm/rounding differences.  A path can diverge when an
     ulp flips a comparison, so a small fraction of pixels may differ by more; none may differ in the mean.
     Tolerance: >= 97 % of pixels within 1e-3 relative (+1e-4 absolute), image mean within 1 %."""
     hs = HostScene("cornell_box", nx / ny)
     sc = Scene(hs, 0)
+    sc.set_path(render=PATHS[path])
     g = gpu_render(sc, nx, ny, 0, ns, sub_samples=nss, max_depth=depth, seed=3)
+    assert sc.info(_capi.RT_INFO_LAST_RENDER_PATH) == PATHS[path]
     c, _, _ = O.render(hs, nx, ny, 0, ns, nss, depth, O.ORC_RNG_COUNTER, 3, 8)
     assert np.all(g[..., 0] == ns) and np.all(c[..., 0] == ns)
     close = np.isclose(g[..., 1:], c[..., 1:], rtol=1e-3, atol=1e-4).all(axis=-1)
