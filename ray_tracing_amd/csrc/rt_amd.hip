@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S
     bool alive = false;
     Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
     V3 T = v3(1, 1, 1);
-    Rng rng{0u, 0u};
+    Rng rng{0u};
     int depth = 0, pix = lane;
 
     for (;;) {
@@ -89,8 +89,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S
                 const int sub = q - (q / A.sub_samples) * A.sub_samples;
                 const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3); // row 0 = image top
                 if (col < A.nx && row < A.ny) {
-                    rng.key = rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub));
-                    rng.n = 0;
+                    rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
                     // compute_one_sample_task::run, src/main.cpp:230-233; j counts rows from the bottom
                     const int j = A.ny - 1 - row;
                     const float u = float(col + rng.next()) / float(A.nx);
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, int n, const flo
     int k = alive ? i : 0;
     const float *f = rays + 7 * (size_t)k;
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
-    Rng rng{rt_path_key(seed, (uint32_t)k, 0u), 0u};
+    Rng rng{rt_path_key(seed, (uint32_t)k, 0u)};
     Hit h;
     bool any = world_hit(S, r, t_min, t_max, alive, rng, h);
     if (!alive) return;
@@ -204,6 +203,7 @@ __device__ __forceinline__ void load_records(const uint32_t *__restrict__ recs, 
     R.d[0] = a.x, R.d[1] = a.y, R.d[2] = a.z, R.d[3] = a.w, R.d[4] = b.x, R.d[5] = b.y, R.d[6] = b.z, R.d[7] = b.w;
 }
 
+template <bool TEX>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevScene S, const uint32_t *__restrict__ recs,
                                                                             rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
 {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
     bool alive = false;
     Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
     V3 T = v3(1, 1, 1);
-    Rng rng{0u, 0u};
+    Rng rng{0u};
     int depth = 0, pix = lane;
 
     for (;;) {
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
             if (!alive && item < total) {
                 pix = item & 63;
                 const int q = item >> 6;
-                const int sample = A.sample_begin + s0 + q / A.sub_samples;
-                const int sub = q - (q / A.sub_samples) * A.sub_samples;
+                const int qs = A.sub_samples == 1 ? q : q / A.sub_samples; // the division only when it is needed
+                const int sample = A.sample_begin + s0 + qs;
+                const int sub = q - qs * A.sub_samples;
                 const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
                 if (col < A.nx && row < A.ny) {
-                    rng.key = rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub));
-                    rng.n = 0;
+                    rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
                     const int j = A.ny - 1 - row;
                     const float u = (float(col) + rng.next()) * inv_nx;
                     const float v = (float(j) + rng.next()) * inv_ny;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
 
         if (alive) {
             V3 L;
-            if (!rtf::shade(S, R, Y, rec >= 0, sf, r, T, depth, A.max_depth, rng, L)) {
+            if (!rtf::shade<TEX>(S, R, Y, rec >= 0, sf, r, T, depth, A.max_depth, rng, L)) {
                 alive = false;
                 if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
                 if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
@@ -338,6 +338,7 @@ struct rt_scene {
     bool timed = false;
     // register-resident form (rt_records.h), when the scene fits
     bool fast_ok = false;
+    bool fast_textured = false; // some material's texture is not a constant
     const char *fast_why = "";
     rtf::Layout layout{0, 0, 0, 0};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids (inside blob)
@@ -513,6 +514,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     D.n_entries = d->n_entries, D.n_lights = d->n_lights;
     D.cam = d->camera;
     s->fast_ok = fast_ok, s->fast_why = why;
+    for (int m = 0; fast_ok && m < d->n_materials; ++m)
+        s->fast_textured |= (int32_t)tab.rec[tab.materials_base + m][1] >= 0;
     s->d_records = (uint32_t *)(b + parts[8].off);
     s->d_rec_user = (int32_t *)(b + parts[9].off);
     s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights};
@@ -581,8 +584,10 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     if (A.atomic_out && !accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
     const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     RT_HIP(hipEventRecord(s->ev0, stream));
-    if (use_fast)
-        hipLaunchKernelGGL(render_fast_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    if (use_fast && s->fast_textured)
+        hipLaunchKernelGGL(render_fast_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    else if (use_fast)
+        hipLaunchKernelGGL(render_fast_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
     else
         hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
     RT_HIP(hipGetLastError());

@@ -74,9 +74,16 @@ struct Onb { // src/vec3.h:195-224
 };
 
 // per-path random stream, include/rt_rng.h
+// rt_draw(key, n) hashes key + n * 0x9E3779B9; the sum is carried instead of recomputed.
 struct Rng {
-    uint32_t key, n;
-    RT_DEV float next() { return rt_draw(key, n++); }
+    uint32_t x;
+    RT_DEV void start(uint32_t key) { x = key; }
+    RT_DEV float next()
+    {
+        const uint32_t h = rt_mix32(x);
+        x += 0x9E3779B9U;
+        return (float)(h >> 8) * (1.0f / 16777216.0f);
+    }
 };
 
 // ---------------------------------------------------------------------------

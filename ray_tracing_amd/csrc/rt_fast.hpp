@@ -111,6 +111,17 @@ RTF_DEV void apply_chain(const Regs &R, uint32_t chain_bits, const Ray &wr, Loca
 // bound shrinks from member to member, then the list's result competes like any leaf:
 // it replaces the best so far unless the best is strictly nearer (src/bvh.h:132-139).
 // ---------------------------------------------------------------------------
+// One rect record against the ray of its chain.  Straight-line code per axis (the axis is
+// wave-uniform); bitwise & on purpose: && would make hipcc branch around every comparison.
+RTF_DEV bool rect_in(const Regs &R, int i, float ok, float ik, float oa, float da, float ob, float db, float t_min,
+                     float bound, float &t)
+{
+    t = (rl_f(R.d[4], i) - ok) * ik;
+    const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
+    return (t >= t_min) & (t <= bound) & (a >= rl_f(R.d[0], i)) & (a <= rl_f(R.d[1], i)) & (b >= rl_f(R.d[2], i)) &
+           (b <= rl_f(R.d[3], i));
+}
+
 RTF_DEV void scan(const Regs &R, const Layout &Y, const Ray &wr, float t_min, float t_max, bool alive, float &best_t,
                   int &best_rec)
 {
@@ -125,10 +136,13 @@ RTF_DEV void scan(const Regs &R, const Layout &Y, const Ray &wr, float t_min, fl
     float gt = t_max; // bound and winner inside the current list
     int grec = -1;
 
-    for (int i = 0; i < Y.n_stream;) {
+    // A plain counted loop keeps i in an SGPR.  A lane that missed a box carries `resume`, the index
+    // after that subtree; when every lane is skipping, a record costs one readlane and one branch.
+    for (int i = 0; i < Y.n_stream; ++i) {
+        const bool on = alive & (resume <= i);
+        if (__ballot(on) == 0ull) continue;
         const uint32_t kw = rl_u(R.d[7], i);
         const uint32_t kind = kw & 15u;
-        const bool on = alive && resume <= i;
         if (kind != RT_REC_SPHERE) {
             const uint32_t chain = (kw >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK;
             if (chain != cur_chain) {
@@ -143,25 +157,19 @@ RTF_DEV void scan(const Regs &R, const Layout &Y, const Ray &wr, float t_min, fl
             const float z0 = (rl_f(R.d[2], i) - l.o.z) * l.inv.z, z1 = (rl_f(R.d[6], i) - l.o.z) * l.inv.z;
             const float tn = fmaxf(fmax3(fminf(x0, x1), fminf(y0, y1), fminf(z0, z1)), t_min);
             const float tf = fminf(fmin3(fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1)), t_max);
-            const bool in = tf > tn;
             const int skip = (int)rl_u(R.d[3], i);
-            if (on && !in) resume = skip;
-            i = __any(on && in) ? i + 1 : skip;
+            resume = (on & !(tf > tn)) ? skip : resume;
             continue;
         }
-        if (kw & RT_KW_FIRST) gt = t_max, grec = -1;
+        const bool single = (kw & (RT_KW_FIRST | RT_KW_LAST)) == (RT_KW_FIRST | RT_KW_LAST);
+        const float bound = (kw & RT_KW_FIRST) ? t_max : gt;
+        float t;
+        bool in;
         if (kind == RT_REC_RECT) { // src/plane.h:9-29, 47-67, 109-129
             const uint32_t axis = (kw >> RT_KW_AXIS_SHIFT) & 3u;
-            float ok, ik, oa, da, ob, db;
-            if (axis == 0) ok = l.o.z, ik = l.inv.z, oa = l.o.x, da = l.d.x, ob = l.o.y, db = l.d.y;
-            else if (axis == 1) ok = l.o.y, ik = l.inv.y, oa = l.o.x, da = l.d.x, ob = l.o.z, db = l.d.z;
-            else ok = l.o.x, ik = l.inv.x, oa = l.o.y, da = l.d.y, ob = l.o.z, db = l.d.z;
-            const float t = (rl_f(R.d[4], i) - ok) * ik;
-            const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
-            const bool in = on && t >= t_min && t <= gt && a >= rl_f(R.d[0], i) && a <= rl_f(R.d[1], i) &&
-                            b >= rl_f(R.d[2], i) && b <= rl_f(R.d[3], i);
-            gt = in ? t : gt;
-            grec = in ? i : grec;
+            if (axis == 0) in = rect_in(R, i, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, t_min, bound, t);
+            else if (axis == 1) in = rect_in(R, i, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, t_min, bound, t);
+            else in = rect_in(R, i, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, t_min, bound, t);
         } else { // sphere, world space: src/sphere.h:21-59
             const V3 oc = v3(wr.o.x - rl_f(R.d[0], i), wr.o.y - rl_f(R.d[1], i), wr.o.z - rl_f(R.d[2], i));
             const float radius = rl_f(R.d[3], i);
@@ -170,17 +178,25 @@ RTF_DEV void scan(const Regs &R, const Layout &Y, const Ray &wr, float t_min, fl
             const float disc = fmaf(b, b, -(w_dd * c));
             const float sq = fsqrt(disc);
             const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
-            const bool in1 = t1 < gt && t1 > t_min, in2 = t2 < gt && t2 > t_min;
-            const bool in = on && disc > 0.0f && (in1 || in2);
-            gt = in ? (in1 ? t1 : t2) : gt;
+            const bool in1 = (t1 < bound) & (t1 > t_min), in2 = (t2 < bound) & (t2 > t_min);
+            in = (disc > 0.0f) & (in1 | in2);
+            t = in1 ? t1 : t2;
+        }
+        in = in & on;
+        if (single) { // a leaf of its own: competes directly (src/bvh.h:130-151)
+            const bool take = in & (t <= best_t);
+            best_t = take ? t : best_t;
+            best_rec = take ? i : best_rec;
+        } else { // member of a list: hitable_list::hit, src/hitable_list.h:18-34
+            grec = (kw & RT_KW_FIRST) ? -1 : grec;
+            gt = in ? t : bound;
             grec = in ? i : grec;
+            if (kw & RT_KW_LAST) {
+                const bool take = (grec >= 0) & (gt <= best_t);
+                best_t = take ? gt : best_t;
+                best_rec = take ? grec : best_rec;
+            }
         }
-        if (kw & RT_KW_LAST) {
-            const bool take = grec >= 0 && gt <= best_t;
-            best_t = take ? gt : best_t;
-            best_rec = take ? grec : best_rec;
-        }
-        ++i;
     }
 }
 
@@ -320,13 +336,15 @@ RTF_DEV V3 lights_random(const Regs &R, const Layout &Y, V3 o, Rng &rng)
 }
 
 // One bounce of color() (src/main.cpp:91-127) in throughput form; see rt::shade for the derivation.
+// TEX: the scene has a non-constant texture (noise / checker); those are evaluated from the memory tables.
+template <bool TEX>
 RTF_DEV bool shade(const DevScene &S, const Regs &R, const Layout &Y, bool hit_any, const Surface &h, Ray &r, V3 &T,
                    int &depth, int max_depth, Rng &rng, V3 &L)
 {
     L = v3(0, 0, 0);
     if (!hit_any) return false;
     V3 albedo = h.color;
-    if (h.texture >= 0) albedo = rt::tex_value(S, h.texture, 0.0f, 0.0f, h.p); // noise / checker: memory path
+    if (TEX && h.texture >= 0) albedo = rt::tex_value(S, h.texture, 0.0f, 0.0f, h.p);
     if (h.mat_kind == RT_MAT_DIFFUSE_LIGHT) {
         L = v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
         return false;

@@ -15,7 +15,7 @@ for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for f in sorted(glob.glob(os.path.join(d, p, "**", "*counter_collection.csv"), recursive=True)):
         agg = {}
         for r in csv.DictReader(open(f)):
-            if "render_kernel" not in r["Kernel_Name"]:
+            if "render_" not in r["Kernel_Name"]:
                 continue
             k = r["Counter_Name"]
             agg.setdefault(k, []).append(float(r["Counter_Value"]))
