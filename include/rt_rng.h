@@ -12,6 +12,9 @@
  * path (jitter u, jitter v, lens disk, shutter time, then per bounce: media met
  * during traversal, then the material / pdf draws).  The CPU oracle can run on
  * this same stream, which makes per-pixel comparison possible.
+ * One deliberate difference: when the camera's lens radius is exactly zero the
+ * lens-disk rejection loop is not run at all (the reference draws it and then
+ * multiplies the point by zero, src/camera.h:56), so no draws are spent on it.
  *
  * This header is plain C and is included by host code, the oracle and the HIP
  * kernels alike; it is part of the ABI (changing it changes every image).

@@ -595,7 +595,10 @@ Ray get_ray(const rt_camera &c, float s, float t, Rng &rng)
     V3 origin = v3(c.origin[0], c.origin[1], c.origin[2]);
     V3 llc = v3(c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2]);
     V3 hor = v3(c.horizontal[0], c.horizontal[1], c.horizontal[2]), ver = v3(c.vertical[0], c.vertical[1], c.vertical[2]);
-    V3 rd = c.lens_radius * random_in_unit_disk(rng);
+    // per-path stream (include/rt_rng.h): no lens draws when they cannot matter; the reference's own
+    // stream (MINSTD mode) always draws them, as src/camera.h:56 does
+    V3 disk = (rng.mode == ORC_RNG_COUNTER && c.lens_radius == 0.0f) ? v3(0, 0, 0) : random_in_unit_disk(rng);
+    V3 rd = c.lens_radius * disk;
     V3 offset = cu * rd.x + cv * rd.y;
     V3 oo = origin + offset;
     float time = c.time0 + rng.next() * (c.time1 - c.time0);

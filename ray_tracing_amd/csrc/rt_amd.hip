@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S
                     const int j = A.ny - 1 - row;
                     const float u = float(col + rng.next()) / float(A.nx);
                     const float v = float(j + rng.next()) / float(A.ny);
-                    const V3 disk = random_in_unit_disk(rng);
+                    const V3 disk = S.cam.lens_radius == 0.0f ? v3(0, 0, 0) : random_in_unit_disk(rng); // include/rt_rng.h
                     const float time01 = rng.next();
                     r = camera_ray(S.cam, u, v, disk, time01);
                     T = v3(1, 1, 1);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
                     const int j = A.ny - 1 - row;
                     const float u = (float(col) + rng.next()) * inv_nx;
                     const float v = (float(j) + rng.next()) * inv_ny;
-                    const V3 disk = rtf::rnd_unit_disk(rng);
+                    const V3 disk = S.cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
                     const float time01 = rng.next();
                     r = rtf::camera_ray(S.cam, u, v, disk, time01);
                     T = v3(1, 1, 1);

@@ -64,10 +64,21 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             chains_used.push_back(c);
         }
     };
+    // A box test pays when it lets the WHOLE wave jump over a subtree.  With incoherent rays and
+    // a handful of primitives that never happens, and the 64 lanes test every primitive anyway:
+    // such scenes are stored without their inner nodes (a box only ever culls, it never adds a hit).
+    int n_leaf_records = 0;
+    for (int e = 0; e < d->n_entries; ++e)
+        if ((d->entries[e].b & 255) == RT_ENTRY_LEAF) {
+            const rt_prim &p = d->prims[d->entries[e].a];
+            n_leaf_records += p.kind == RT_PRIM_GROUP ? p.count : 1;
+        }
+    const bool keep_inner = n_leaf_records > RT_REC_FLAT_LEAVES;
     for (int e = 0; e < d->n_entries; ++e) {
         map[e] = n_stream;
         const rt_entry &en = d->entries[e];
         if ((en.b & 255) == RT_ENTRY_INNER) {
+            if (!keep_inner) continue;
             use_chain(en.b >> 8);
             ++n_stream;
             continue;
@@ -182,6 +193,7 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
         const rt_entry &en = d->entries[e];
         int s = map[e];
         if ((en.b & 255) == RT_ENTRY_INNER) {
+            if (!keep_inner) continue;
             uint32_t *r = out->rec[s];
             for (int k = 0; k < 3; ++k) r[k] = fbits(en.lo[k]), r[4 + k] = fbits(en.hi[k]);
             r[3] = (uint32_t)map[en.a];

@@ -27,6 +27,7 @@
 #include "../../include/rt_amd.h"
 
 #define RT_REC_MAX 64
+#define RT_REC_FLAT_LEAVES 16 /* scenes with at most this many primitive records are stored without inner nodes */
 
 enum rt_rec_kind {
     RT_REC_INNER = 0,
