@@ -266,13 +266,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
 
         float t;
         int rec;
-        rtf::scan(R, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
+        rtf::scan(recs, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
         rtf::Surface sf;
         rtf::build_surface(R, Y, r, t, rec, sf); // every lane takes part in the cross-lane fetches
 
         if (alive) {
             V3 L;
-            if (!rtf::shade<TEX>(S, R, Y, rec >= 0, sf, r, T, depth, A.max_depth, rng, L)) {
+            if (!rtf::shade<TEX>(S, recs, Y, rec >= 0, sf, r, T, depth, A.max_depth, rng, L)) {
                 alive = false;
                 if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
                 if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
     float t;
     int rec;
-    rtf::scan(R, Y, r, t_min, t_max, alive, t, rec);
+    rtf::scan(recs, Y, r, t_min, t_max, alive, t, rec);
     rtf::Surface sf;
     rtf::build_surface(R, Y, r, t, rec, sf);
     const uint32_t kw = rtf::sh_u(R.d[7], rec < 0 ? 0 : rec);

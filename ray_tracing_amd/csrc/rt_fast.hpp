@@ -84,17 +84,32 @@ RTF_DEV void set_local(LocalRay &l, V3 o, V3 d)
     l.inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
 }
 
+// One stream record in SGPRs.  The scan reads the record table with wave-uniform scalar loads
+// (s_load_dwordx8 from the 2 KiB table, which stays in the scalar cache) and always has the NEXT
+// record's load in flight while it works on the current one, so the loads cost the VALU nothing.
+// (v_readlane from the register-resident copy would cost a VALU slot per dword: six per record.)
+struct SRec {
+    uint32_t d[8];
+};
+RTF_DEV SRec load_rec(const uint32_t *__restrict__ recs, int i)
+{
+    const uint4 a = reinterpret_cast<const uint4 *>(recs)[2 * i], b = reinterpret_cast<const uint4 *>(recs)[2 * i + 1];
+    SRec r;
+    r.d[0] = a.x, r.d[1] = a.y, r.d[2] = a.z, r.d[3] = a.w, r.d[4] = b.x, r.d[5] = b.y, r.d[6] = b.z, r.d[7] = b.w;
+    return r;
+}
+RTF_DEV float sf(const SRec &r, int k) { return __uint_as_float(r.d[k]); }
+
 // translate::hit / rotate_y::hit on the way down (src/transforms.h:17, 107-110), operations from records
-RTF_DEV void apply_chain(const Regs &R, uint32_t chain_bits, const Ray &wr, LocalRay &l)
+RTF_DEV void apply_chain(const uint32_t *__restrict__ recs, uint32_t chain_bits, const Ray &wr, LocalRay &l)
 {
     V3 o = wr.o, d = wr.d;
     const int first = chain_bits & 63, count = chain_bits >> 6;
     for (int k = 0; k < count; ++k) {
-        const uint32_t kind = rl_u(R.d[7], first + k) & 15u;
-        const float a = rl_f(R.d[0], first + k), b = rl_f(R.d[1], first + k);
-        if (kind == RT_REC_XFORM_T) {
-            const float c = rl_f(R.d[2], first + k);
-            o = v3(o.x - a, o.y - b, o.z - c);
+        const SRec x = load_rec(recs, first + k);
+        const float a = sf(x, 0), b = sf(x, 1);
+        if ((x.d[7] & 15u) == RT_REC_XFORM_T) {
+            o = v3(o.x - a, o.y - b, o.z - sf(x, 2));
         } else { // a = sin, b = cos
             const float ox = b * o.x - a * o.z, oz = a * o.x + b * o.z;
             const float dx = b * d.x - a * d.z, dz = a * d.x + b * d.z;
@@ -113,17 +128,16 @@ RTF_DEV void apply_chain(const Regs &R, uint32_t chain_bits, const Ray &wr, Loca
 // ---------------------------------------------------------------------------
 // One rect record against the ray of its chain.  Straight-line code per axis (the axis is
 // wave-uniform); bitwise & on purpose: && would make hipcc branch around every comparison.
-RTF_DEV bool rect_in(const Regs &R, int i, float ok, float ik, float oa, float da, float ob, float db, float t_min,
-                     float bound, float &t)
+RTF_DEV bool rect_in(const SRec &c, float ok, float ik, float oa, float da, float ob, float db, float t_min, float bound,
+                     float &t)
 {
-    t = (rl_f(R.d[4], i) - ok) * ik;
+    t = (sf(c, 4) - ok) * ik;
     const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
-    return (t >= t_min) & (t <= bound) & (a >= rl_f(R.d[0], i)) & (a <= rl_f(R.d[1], i)) & (b >= rl_f(R.d[2], i)) &
-           (b <= rl_f(R.d[3], i));
+    return (t >= t_min) & (t <= bound) & (a >= sf(c, 0)) & (a <= sf(c, 1)) & (b >= sf(c, 2)) & (b <= sf(c, 3));
 }
 
-RTF_DEV void scan(const Regs &R, const Layout &Y, const Ray &wr, float t_min, float t_max, bool alive, float &best_t,
-                  int &best_rec)
+RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray &wr, float t_min, float t_max,
+                  bool alive, float &best_t, int &best_rec)
 {
     best_t = __builtin_inff();
     best_rec = -1;
@@ -137,27 +151,30 @@ RTF_DEV void scan(const Regs &R, const Layout &Y, const Ray &wr, float t_min, fl
     int grec = -1;
 
     // A plain counted loop keeps i in an SGPR.  A lane that missed a box carries `resume`, the index
-    // after that subtree; when every lane is skipping, a record costs one readlane and one branch.
+    // after that subtree; when every lane is skipping, a record costs one compare and one branch.
+    SRec nxt = load_rec(recs, 0);
     for (int i = 0; i < Y.n_stream; ++i) {
+        const SRec c = nxt;
+        nxt = load_rec(recs, i + 1); // the table is padded: record n_stream exists
         const bool on = alive & (resume <= i);
         if (__ballot(on) == 0ull) continue;
-        const uint32_t kw = rl_u(R.d[7], i);
+        const uint32_t kw = c.d[7];
         const uint32_t kind = kw & 15u;
         if (kind != RT_REC_SPHERE) {
             const uint32_t chain = (kw >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK;
             if (chain != cur_chain) {
                 if (chain == 0) l = w;
-                else apply_chain(R, chain, wr, l);
+                else apply_chain(recs, chain, wr, l);
                 cur_chain = chain;
             }
         }
         if (kind == RT_REC_INNER) { // aabb::hit, src/aabb.h:60-83
-            const float x0 = (rl_f(R.d[0], i) - l.o.x) * l.inv.x, x1 = (rl_f(R.d[4], i) - l.o.x) * l.inv.x;
-            const float y0 = (rl_f(R.d[1], i) - l.o.y) * l.inv.y, y1 = (rl_f(R.d[5], i) - l.o.y) * l.inv.y;
-            const float z0 = (rl_f(R.d[2], i) - l.o.z) * l.inv.z, z1 = (rl_f(R.d[6], i) - l.o.z) * l.inv.z;
+            const float x0 = (sf(c, 0) - l.o.x) * l.inv.x, x1 = (sf(c, 4) - l.o.x) * l.inv.x;
+            const float y0 = (sf(c, 1) - l.o.y) * l.inv.y, y1 = (sf(c, 5) - l.o.y) * l.inv.y;
+            const float z0 = (sf(c, 2) - l.o.z) * l.inv.z, z1 = (sf(c, 6) - l.o.z) * l.inv.z;
             const float tn = fmaxf(fmax3(fminf(x0, x1), fminf(y0, y1), fminf(z0, z1)), t_min);
             const float tf = fminf(fmin3(fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1)), t_max);
-            const int skip = (int)rl_u(R.d[3], i);
+            const int skip = (int)c.d[3];
             resume = (on & !(tf > tn)) ? skip : resume;
             continue;
         }
@@ -167,15 +184,15 @@ RTF_DEV void scan(const Regs &R, const Layout &Y, const Ray &wr, float t_min, fl
         bool in;
         if (kind == RT_REC_RECT) { // src/plane.h:9-29, 47-67, 109-129
             const uint32_t axis = (kw >> RT_KW_AXIS_SHIFT) & 3u;
-            if (axis == 0) in = rect_in(R, i, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, t_min, bound, t);
-            else if (axis == 1) in = rect_in(R, i, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, t_min, bound, t);
-            else in = rect_in(R, i, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, t_min, bound, t);
+            if (axis == 0) in = rect_in(c, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, t_min, bound, t);
+            else if (axis == 1) in = rect_in(c, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, t_min, bound, t);
+            else in = rect_in(c, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, t_min, bound, t);
         } else { // sphere, world space: src/sphere.h:21-59
-            const V3 oc = v3(wr.o.x - rl_f(R.d[0], i), wr.o.y - rl_f(R.d[1], i), wr.o.z - rl_f(R.d[2], i));
-            const float radius = rl_f(R.d[3], i);
+            const V3 oc = v3(wr.o.x - sf(c, 0), wr.o.y - sf(c, 1), wr.o.z - sf(c, 2));
+            const float radius = sf(c, 3);
             const float b = fdot(oc, wr.d);
-            const float c = fmaf(-radius, radius, fdot(oc, oc));
-            const float disc = fmaf(b, b, -(w_dd * c));
+            const float cc = fmaf(-radius, radius, fdot(oc, oc));
+            const float disc = fmaf(b, b, -(w_dd * cc));
             const float sq = fsqrt(disc);
             const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
             const bool in1 = (t1 < bound) & (t1 > t_min), in2 = (t2 < bound) & (t2 > t_min);
@@ -267,31 +284,30 @@ struct Onb {
 };
 
 // hitable_list::pdf_value over the light records, src/hitable_list.h:67-77
-RTF_DEV float lights_pdf_value(const Regs &R, const Layout &Y, V3 o, V3 v)
+RTF_DEV float lights_pdf_value(const uint32_t *__restrict__ recs, const Layout &Y, V3 o, V3 v)
 {
     const float weight = rcp((float)Y.n_lights);
     const float vv = fdot(v, v);
     float sum = 0.0f;
     for (int k = 0; k < Y.n_lights; ++k) {
-        const int i = Y.lights_base + k;
-        const uint32_t kind = rl_u(R.d[7], i) & 15u;
+        const SRec c = load_rec(recs, Y.lights_base + k);
+        const uint32_t kind = c.d[7] & 15u;
         float pdf = 0.0f;
         if (kind == RT_REC_LIGHT_RECT) { // xz_rect::pdf_value, src/plane.h:76-91
-            const float t = (rl_f(R.d[4], i) - o.y) * rcp(v.y);
+            const float t = (sf(c, 4) - o.y) * rcp(v.y);
             const float x = fmaf(t, v.x, o.x), z = fmaf(t, v.z, o.z);
-            const bool in = t >= 0.0001f && x >= rl_f(R.d[0], i) && x <= rl_f(R.d[1], i) && z >= rl_f(R.d[2], i) &&
-                            z <= rl_f(R.d[3], i);
+            const bool in = (t >= 0.0001f) & (x >= sf(c, 0)) & (x <= sf(c, 1)) & (z >= sf(c, 2)) & (z <= sf(c, 3));
             const float cosine = fabsf(v.y) * rsq(vv);
-            pdf = in ? t * t * vv * rcp(cosine * rl_f(R.d[5], i)) : 0.0f;
+            pdf = in ? t * t * vv * rcp(cosine * sf(c, 5)) : 0.0f;
         } else if (kind == RT_REC_LIGHT_SPHERE) { // sphere::pdf_value, src/sphere.h:68-83
-            const V3 oc = v3(o.x - rl_f(R.d[0], i), o.y - rl_f(R.d[1], i), o.z - rl_f(R.d[2], i));
-            const float radius = rl_f(R.d[3], i);
+            const V3 oc = v3(o.x - sf(c, 0), o.y - sf(c, 1), o.z - sf(c, 2));
+            const float radius = sf(c, 3);
             const float b = fdot(oc, v), occ = fdot(oc, oc);
-            const float c = fmaf(-radius, radius, occ);
-            const float disc = fmaf(b, b, -(vv * c));
+            const float cc = fmaf(-radius, radius, occ);
+            const float disc = fmaf(b, b, -(vv * cc));
             const float sq = fsqrt(disc), ia = rcp(vv);
             const float t1 = (-b - sq) * ia, t2 = (-b + sq) * ia;
-            const bool in = disc > 0.0f && (t1 > 0.001f || t2 > 0.001f);
+            const bool in = (disc > 0.0f) & ((t1 > 0.001f) | (t2 > 0.001f));
             const float cos_theta_max = fsqrt(1.0f - radius * radius * rcp(occ));
             pdf = in ? rcp(2.0f * RT_PI * (1.0f - cos_theta_max)) : 0.0f;
         }
@@ -300,20 +316,21 @@ RTF_DEV float lights_pdf_value(const Regs &R, const Layout &Y, V3 o, V3 v)
     return sum;
 }
 // hitable_list::random, src/hitable_list.h:79-88: the member is chosen per lane
-RTF_DEV V3 lights_random(const Regs &R, const Layout &Y, V3 o, Rng &rng)
+RTF_DEV V3 lights_random(const uint32_t *__restrict__ recs, const Layout &Y, V3 o, Rng &rng)
 {
     int index = (int)(rng.next() * (float)Y.n_lights);
     if (index == Y.n_lights) index--;
-    // This runs under a divergent branch, where ds_bpermute would return 0 for records held by
-    // inactive lanes; v_readlane ignores EXEC, so walk the (few) lights and keep the chosen one.
+    // The member is chosen per lane; the (few) light records are read with wave-uniform scalar loads
+    // and each lane keeps the one it drew.  (ds_bpermute from the register-resident table must not be
+    // used here: under a divergent branch it returns 0 for records held by inactive lanes.)
     uint32_t kind = RT_REC_LIGHT_NONE;
     float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f, f3 = 0.0f, f4 = 0.0f;
     for (int k = 0; k < Y.n_lights; ++k) {
-        const int i = Y.lights_base + k;
+        const SRec c = load_rec(recs, Y.lights_base + k);
         const bool mine = index == k;
-        kind = mine ? (rl_u(R.d[7], i) & 15u) : kind;
-        f0 = mine ? rl_f(R.d[0], i) : f0, f1 = mine ? rl_f(R.d[1], i) : f1, f2 = mine ? rl_f(R.d[2], i) : f2;
-        f3 = mine ? rl_f(R.d[3], i) : f3, f4 = mine ? rl_f(R.d[4], i) : f4;
+        kind = mine ? (c.d[7] & 15u) : kind;
+        f0 = mine ? sf(c, 0) : f0, f1 = mine ? sf(c, 1) : f1, f2 = mine ? sf(c, 2) : f2;
+        f3 = mine ? sf(c, 3) : f3, f4 = mine ? sf(c, 4) : f4;
     }
     if (kind == RT_REC_LIGHT_RECT) { // xz_rect::random, src/plane.h:94-98 (z takes the first draw)
         const float rz = rng.next(), rx = rng.next();
@@ -338,7 +355,7 @@ RTF_DEV V3 lights_random(const Regs &R, const Layout &Y, V3 o, Rng &rng)
 // One bounce of color() (src/main.cpp:91-127) in throughput form; see rt::shade for the derivation.
 // TEX: the scene has a non-constant texture (noise / checker); those are evaluated from the memory tables.
 template <bool TEX>
-RTF_DEV bool shade(const DevScene &S, const Regs &R, const Layout &Y, bool hit_any, const Surface &h, Ray &r, V3 &T,
+RTF_DEV bool shade(const DevScene &S, const uint32_t *__restrict__ recs, const Layout &Y, bool hit_any, const Surface &h, Ray &r, V3 &T,
                    int &depth, int max_depth, Rng &rng, V3 &L)
 {
     L = v3(0, 0, 0);
@@ -356,7 +373,7 @@ RTF_DEV bool shade(const DevScene &S, const Regs &R, const Layout &Y, bool hit_a
         uvw.build_from_w(h.n);
         V3 dir;
         if (rng.next() < 0.5f) {
-            dir = funit(lights_random(R, Y, h.p, rng));
+            dir = funit(lights_random(recs, Y, h.p, rng));
         } else { // cosine_pdf::generate with random_cosine_direction's factor 2 (src/vec3.h:179-180)
             const float r1 = rng.next();
             const float r2 = rng.next();
@@ -367,7 +384,7 @@ RTF_DEV bool shade(const DevScene &S, const Regs &R, const Layout &Y, bool hit_a
         }
         const float cosine = fdot(dir, uvw.w);
         const float cos_val = cosine > 0.0f ? cosine * (1.0f / RT_PI) : 0.0f;
-        const float pdf_val = 0.5f * lights_pdf_value(R, Y, h.p, dir) + 0.5f * cos_val;
+        const float pdf_val = 0.5f * lights_pdf_value(recs, Y, h.p, dir) + 0.5f * cos_val;
         const float sc = fmaxf(fdot(h.n, dir), 0.0f) * (1.0f / RT_PI);
         const float wgt = sc * rcp(pdf_val);
         T = v3(T.x * albedo.x * wgt, T.y * albedo.y * wgt, T.z * albedo.z * wgt);

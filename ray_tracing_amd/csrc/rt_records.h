@@ -51,7 +51,7 @@ enum rt_rec_kind {
 #define RT_KW_MAT_MASK 0xffu
 
 typedef struct rt_record_table {
-    uint32_t rec[RT_REC_MAX][8];
+    uint32_t rec[RT_REC_MAX + 1][8]; /* one spare record: the scan prefetches record i+1 */
     int32_t user_id[RT_REC_MAX]; /* rt_prim.user_id of primitive records (for rt_trace_rays) */
     int32_t prim[RT_REC_MAX];    /* rt_prim index of primitive records */
     int32_t n_stream;            /* records [0, n_stream) are the traversal stream */
