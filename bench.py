@@ -63,6 +63,16 @@ def cpu_baseline():
             "sample": f"oracle/librt_oracle.so Cornell 256x256 64 spp depth 50, {cores} threads, per-path RNG"}
 
 
+def traffic_from_profile():
+    """HBM bytes per launch of the render kernel on the headline workload, from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE, both reported in KiB); None if not profiled."""
+    path = os.path.join(ROOT, "profiles", "headline_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,7 +85,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ray_tracing_amd import api
+    from ray_tracing_amd import api, distributed as D
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,15 +99,14 @@ def main():
 
     nx = ny = a.size
     spp = a.spp
-    s0, s1 = rank * spp // world, (rank + 1) * spp // world  # disjoint sample ranges
+    s0, s1 = D.sample_range(rank, world, spp)  # disjoint sample ranges
     scene = api.Scene(api.HostScene("cornell_box", nx / ny), local)
     accum = torch.empty((ny, nx, 4), dtype=torch.float32, device=dev)
     image = torch.empty((ny, nx), dtype=torch.int32, device=dev)
 
     def step():
         api.render(scene, accum, nx, ny, s0, s1, max_depth=DEPTH, seed=0)
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        D.reduce_accumulators(accum, 0)
         if rank == 0:
             api.resolve(accum, image)
 
@@ -110,11 +119,9 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-        kernel_ms.append(None)
     fence()
     dt = time.perf_counter() - t0
     # kernel duration from the HIP events rt_render records on its launch stream (last step; steps are identical)
@@ -125,6 +132,8 @@ def main():
     dt, k_ms = float(t[0]), float(t[1])
 
     if rank == 0:
+        from ray_tracing_amd import _capi
+        kernel = ("render_fast_kernel" if scene.info(_capi.RT_INFO_LAST_RENDER_PATH) == _capi.RT_PATH_FAST else "render_kernel")
         sec_per_step = dt / a.steps
         paths = nx * ny * spp
         value = paths / sec_per_step / 1e6
@@ -138,8 +147,8 @@ def main():
             "config": {"workload": f"cornell_box {nx}x{ny} {spp}spp depth {DEPTH} (BASELINE.json configs[1])",
                        "partition": f"disjoint spp ranges over {world} GPU(s) + one RCCL sum-reduce of float4[{nx}*{ny}]"},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 4), "peak": FP32_VECTOR_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 5), "traffic": None,
-                         "kernel": "render_kernel", "kernel_ms": round(k_ms, 3),
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 5), "traffic": traffic_from_profile(),
+                         "kernel": kernel, "kernel_ms": round(k_ms, 3),
                          "note": "no dense contraction on this path: MFMA unused, FP32 vector peak = FP32 matrix peak"},
         }
         if world == 1 and not a.no_cpu:

@@ -202,3 +202,25 @@ def test_statistical_parity_with_reference_image():
     psnr = 10 * np.log10(255.0 ** 2 / mse)
     print(f"PSNR gpu(4096 spp) vs reference(4096 spp) = {psnr:.2f} dB; mean diff {diff}, 3*SE {3 * se}")
     assert psnr >= 30.0
+
+
+def test_psnr_vs_reference_8192():
+    """BASELINE.json asks for PSNR >= 40 dB against the reference.  Two independent 4096-spp renders differ by
+    35.8 dB from Monte Carlo noise alone (test above), so the comparison that can show 40 dB uses the 8192-spp
+    reference fixture and a GPU render with negligible noise of its own (65 536 spp)."""
+    path = os.path.join(O.GOLD, "cornell_box_256x256_8192spp_r50.npy")
+    if not os.path.exists(path):
+        pytest.skip("8192-spp reference fixture not generated")
+    ref = np.load(path)
+    ny, nx = ref.shape[:2]
+    sc = Scene(HostScene("cornell_box", nx / ny), 0)
+    spp = 65536
+    gpu = gpu_render(sc, nx, ny, 0, spp, seed=33)[..., 1:][..., ::-1] / spp
+    sc.close()
+
+    def to8(x):
+        return np.floor(np.clip(np.sqrt(np.maximum(x, 0)), 0, 1) * 255.99)
+    mse = np.mean((to8(gpu) - to8(ref)) ** 2)
+    psnr = 10 * np.log10(255.0 ** 2 / mse)
+    print(f"PSNR gpu({spp} spp) vs reference(8192 spp) = {psnr:.2f} dB")
+    assert psnr >= 40.0
