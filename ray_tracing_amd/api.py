@@ -39,8 +39,8 @@ class HostScene:
         self.ran01_state = int(lib.rt_host_ran01_state())
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            _capi.load().rt_host_scene_free(self._h)
+        if getattr(self, "_h", None) and _capi is not None and getattr(_capi, "_lib", None) is not None:
+            _capi._lib.rt_host_scene_free(self._h)  # (at interpreter exit the module may already be gone)
             self._h = None
 
 
@@ -73,8 +73,8 @@ class Scene:
         return ms.value
 
     def close(self):
-        if getattr(self, "_s", None):
-            _capi.load().rt_scene_destroy(self._s)
+        if getattr(self, "_s", None) and _capi is not None and getattr(_capi, "_lib", None) is not None:
+            _capi._lib.rt_scene_destroy(self._s)
             self._s = None
 
     __del__ = close

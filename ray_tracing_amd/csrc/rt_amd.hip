@@ -52,6 +52,29 @@ struct RenderArgs {
 
 constexpr int WAVES_PER_BLOCK = 4;
 
+// Tile sums -> HBM: [A, B, G, R] per pixel (src/main.cpp:238-242), col /= sub_samples (src/main.cpp:236).
+// The 8x8 tile is 8 row segments of 128 contiguous bytes.  Lane L moves float L of each 64-float quarter,
+// so one store / atomic instruction covers two whole 128-byte segments (the shape float atomics run at
+// full rate with) instead of 64 lanes each touching one dword of its own 16-byte pixel.
+__device__ __forceinline__ void flush_tile(const float *acc, int lane, int tile_x, int tile_y, const RenderArgs &A, int n_samples,
+                                           float *__restrict__ accum)
+{
+    const float inv = 1.0f / (float)A.sub_samples;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = k * 64 + lane;          // float index inside the tile, row-major, 32 floats per row
+        const int trow = f >> 5, tcol = (f >> 2) & 7, comp = f & 3;
+        const int pix = trow * 8 + tcol;
+        const int col = tile_x * 8 + tcol, row = tile_y * 8 + trow;
+        const float v = comp == 0 ? (float)n_samples : acc[(3 - comp) * 64 + pix] * inv; // B=acc[128..], G=acc[64..], R=acc[0..]
+        if (col < A.nx && row < A.ny) {
+            float *dst = accum + 4 * ((size_t)row * A.nx + col) + comp;
+            if (A.atomic_out) atomicAdd(dst, v);
+            else *dst = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S, RenderArgs A, float *__restrict__ accum)
 {
     __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
@@ -127,18 +150,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S
         }
     }
 
-    // ---- tile sums -> HBM: [A, B, G, R] per pixel (src/main.cpp:238-242) ---------
-    const int col = tile_x * 8 + (lane & 7), row = tile_y * 8 + (lane >> 3);
-    if (col < A.nx && row < A.ny) {
-        const float inv = 1.0f / (float)A.sub_samples; // col /= sub_samples, src/main.cpp:236
-        float4 o = make_float4((float)(s1 - s0), acc[128 + lane] * inv, acc[64 + lane] * inv, acc[lane] * inv);
-        float *dst = accum + 4 * ((size_t)row * A.nx + col);
-        if (A.atomic_out) {
-            atomicAdd(dst + 0, o.x), atomicAdd(dst + 1, o.y), atomicAdd(dst + 2, o.z), atomicAdd(dst + 3, o.w);
-        } else {
-            *reinterpret_cast<float4 *>(dst) = o;
-        }
-    }
+    flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
 }
 
 // src/main.cpp:708-743
@@ -282,17 +294,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
         }
     }
 
-    const int col = tile_x * 8 + (lane & 7), row = tile_y * 8 + (lane >> 3);
-    if (col < A.nx && row < A.ny) {
-        const float inv = 1.0f / (float)A.sub_samples;
-        float4 o = make_float4((float)(s1 - s0), acc[128 + lane] * inv, acc[64 + lane] * inv, acc[lane] * inv);
-        float *dst = accum + 4 * ((size_t)row * A.nx + col);
-        if (A.atomic_out) {
-            atomicAdd(dst + 0, o.x), atomicAdd(dst + 1, o.y), atomicAdd(dst + 2, o.z), atomicAdd(dst + 3, o.w);
-        } else {
-            *reinterpret_cast<float4 *>(dst) = o;
-        }
-    }
+    flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
 }
 
 // world->hit() on the record table (what render_fast_kernel's bounces see)
