@@ -7,7 +7,7 @@ reference's own code; see oracle/ref_harness_tail.cpp for what each mode calls.
 The fixtures are inputs and expected outputs (data), not source.
 
     python oracle/make_golden.py            # everything except the slow converged image
-    python oracle/make_golden.py --image    # + Cornell 256x256 at 4096 spp (about 8 minutes)
+    python oracle/make_golden.py --scenes cornell_box --image   # + Cornell 256x256 at 1024/4096/8192 spp (about 25 minutes)
 """
 import argparse
 import os
@@ -31,27 +31,35 @@ def run(*args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--image", action="store_true", help="also render the 4096-spp converged image")
-    ap.add_argument("--scenes", default="cornell_box")
+    ap.add_argument("--scenes", default="cornell_box,cornell_box_volumes,random_spheres,next_week_final")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
         for scene in a.scenes.split(","):
             out = {}
-            # per-sample float buffers of a `-t 1` run: (ns, ny, nx, 4) = [1,b,g,r]
-            run("samples", scene, 64, 64, 4, 1, 50, f"{tmp}/s.npy")
-            out["samples_64x64_s4_S1_r50"] = np.load(f"{tmp}/s.npy")
-            run("samples", scene, 48, 32, 2, 2, 5, f"{tmp}/s.npy")
-            out["samples_48x32_s2_S2_r5"] = np.load(f"{tmp}/s.npy")
-            # primary rays through pixel centres: see ref_harness_tail.cpp mode_hits for the 20 columns
-            run("hits", scene, 128, 128, f"{tmp}/h.npy")
-            out["hits_128x128"] = np.load(f"{tmp}/h.npy")
-            run("hits", scene, 200, 120, f"{tmp}/h.npy")
-            out["hits_200x120"] = np.load(f"{tmp}/h.npy")
+            if scene == "cornell_box":
+                # per-sample float buffers of a `-t 1` run: (ns, ny, nx, 4) = [1,b,g,r]
+                run("samples", scene, 64, 64, 4, 1, 50, f"{tmp}/s.npy")
+                out["samples_64x64_s4_S1_r50"] = np.load(f"{tmp}/s.npy")
+                run("samples", scene, 48, 32, 2, 2, 5, f"{tmp}/s.npy")
+                out["samples_48x32_s2_S2_r5"] = np.load(f"{tmp}/s.npy")
+                # primary rays through pixel centres: see ref_harness_tail.cpp mode_hits for the 21 columns
+                run("hits", scene, 128, 128, f"{tmp}/h.npy")
+                out["hits_128x128"] = np.load(f"{tmp}/h.npy")
+                run("hits", scene, 200, 120, f"{tmp}/h.npy")
+                out["hits_200x120"] = np.load(f"{tmp}/h.npy")
+                run("tree", scene, os.path.join(GOLD, f"{scene}_tree.txt"))
+            else:
+                # the scenes of ray_tracing_amd/host/rt_scenes_ext.h, compiled against the reference's headers
+                run("samples", scene, 32, 24, 2, 1, 50, f"{tmp}/s.npy")
+                out["samples_32x24_s2_S1_r50"] = np.load(f"{tmp}/s.npy")
+                run("hits", scene, 64, 48, f"{tmp}/h.npy")
+                out["hits_64x48"] = np.load(f"{tmp}/h.npy")
             np.savez_compressed(os.path.join(GOLD, f"{scene}.npz"), **out)
-            run("tree", scene, os.path.join(GOLD, f"{scene}_tree.txt"))
             if a.image:
-                run("image", scene, 256, 256, 4096, 50, f"{tmp}/i.npy")
-                np.save(os.path.join(GOLD, f"{scene}_256x256_4096spp_r50.npy"), np.load(f"{tmp}/i.npy"))
+                for spp in (1024, 4096, 8192):  # 8192 also shows where the reference's minstd stream starts to replay
+                    run("image", scene, 256, 256, spp, 50, f"{tmp}/i.npy")
+                    np.save(os.path.join(GOLD, f"{scene}_256x256_{spp}spp_r50.npy"), np.load(f"{tmp}/i.npy"))
         os.makedirs(f"{tmp}/kat")
         run("kat", f"{tmp}/kat")
         kat = {f[:-4]: np.load(f"{tmp}/kat/{f}") for f in sorted(os.listdir(f"{tmp}/kat"))}

@@ -7,6 +7,37 @@
 #include "../csrc/rt_error.h"
 #include "rt_flatten.h"
 #include "rt_scenes.h"
+#include "rt_scenes_ext.h"
+
+#include <dlfcn.h>
+
+#include <vector>
+
+// Texels of the earth texture (reference: stbi_load("../data/earth.jpg"), src/scenes.h:296).  JPEG decoding is host
+// I/O outside the hot path; the product ships the decoded 1024x512 RGB pixels (ray_tracing_amd/data/, written by
+// `oracle/_ref/ref_harness earth`, i.e. decoded by the reference's own stb_image) and reads them from beside the library.
+unsigned char *rt_ext_earth_pixels(int *nx, int *ny)
+{
+    static std::vector<unsigned char> px;
+    if (px.empty()) {
+        Dl_info info;
+        std::string dir = ".";
+        if (dladdr((void *)&rt_ext_earth_pixels, &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            size_t slash = dir.find_last_of('/');
+            dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+        }
+        std::string path = dir + "/data/earth_1024x512.rgb";
+        if (FILE *f = fopen(path.c_str(), "rb")) {
+            px.resize((size_t)3 * 1024 * 512);
+            if (fread(px.data(), 1, px.size(), f) != px.size()) px.clear();
+            fclose(f);
+        }
+    }
+    if (px.empty()) return nullptr; // the scene is then built without the textured sphere
+    *nx = 1024, *ny = 512;
+    return px.data();
+}
 
 struct rt_host_scene {
     rt_flat_scene flat;
@@ -20,6 +51,9 @@ struct named_scene {
 };
 const named_scene k_scenes[] = {
     {"cornell_box", cornell_box},
+    {"cornell_box_volumes", cornell_box_volumes},
+    {"random_spheres", random_spheres},
+    {"next_week_final", next_week_final},
 };
 uint32_t g_state_after_build = 0;
 } // namespace

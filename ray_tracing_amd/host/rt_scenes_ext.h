@@ -1,0 +1,165 @@
+// rt_scenes_ext.h -- the benchmark scenes that are NOT live in the reference.
+//
+// The reference ships exactly one scene that compiles, cornell_box (src/scenes.h:163-198).  Its other
+// scene functions (src/scenes.h:35-85, 203-229, 234-314) are commented out and use an older API (they
+// return one hitable*, have no important list and no camera).  BASELINE.json's configs 1 and 3 name
+// those scenes, so they are re-stated here against the CURRENT signature
+//     void f( hitable **scene, hitable **important_hitables, camera **cam, float aspect )
+// using nothing but the API both header sets share.  THIS FILE IS COMPILED TWICE: against the reference's
+// own headers inside oracle/_ref/ref_harness (to write golden vectors with the reference's code) and
+// against rt_scene_api.h inside the product (to render on the GPU), so the two sides build the same
+// objects from the same RAN01() stream.
+//
+// What had to be decided because the old functions do not say: every scene needs an important list made of
+// xz_rect / sphere objects (only those implement pdf_value/random, src/hitable.h:19-20), a camera, and,
+// for the book-1 scene, a light (the miss colour is black, src/main.cpp:125).  Each choice is marked DECISION.
+#ifndef RT_SCENES_EXT_H_
+#define RT_SCENES_EXT_H_
+
+#include <cstring>
+
+// provided by whoever includes this file: RGB pixels of data/earth.jpg (1024x512), or nullptr
+unsigned char *rt_ext_earth_pixels(int *nx, int *ny);
+
+// src/scenes.h:203-229 -- the Cornell box with two smoke boxes
+inline void cornell_box_volumes(hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    hitable **list = new hitable *[8];
+    int i = 0;
+    material *red = new lambertian(new constant_texture(vec3(0.65f, 0.05f, 0.05f)));
+    material *white = new lambertian(new constant_texture(vec3(0.73f, 0.73f, 0.73f)));
+    material *green = new lambertian(new constant_texture(vec3(0.12f, 0.45f, 0.15f)));
+    material *light = new diffuse_light(new constant_texture(vec3(15, 15, 15)));
+    list[i++] = new flip_normals(new yz_rect(0, 555, 0, 555, 555, green));
+    list[i++] = new yz_rect(0, 555, 0, 555, 0, red);
+    list[i++] = new flip_normals(new xz_rect(0, 555, 0, 555, 555, white));
+    hitable *lamp = new xz_rect(213, 343, 227, 332, 554, light);
+    list[i++] = lamp;
+    list[i++] = new xz_rect(0, 555, 0, 555, 0, white);
+    list[i++] = new flip_normals(new xy_rect(0, 555, 0, 555, 555, white));
+    hitable *b1 = new translate(new rotate_y(new box(vec3(0, 0, 0), vec3(165, 165, 165), white), -18), vec3(130, 0, 65));
+    hitable *b2 = new translate(new rotate_y(new box(vec3(0, 0, 0), vec3(165, 330, 165), white), 15), vec3(265, 0, 295));
+    list[i++] = new constant_medium(b1, 0.02f, new constant_texture(vec3(1.0f, 1.0f, 1.0f)));
+    list[i++] = new constant_medium(b2, 0.01f, new constant_texture(vec3(0.0f, 0.0f, 0.0f)));
+    hitable **imp = new hitable *[1];
+    imp[0] = lamp; // DECISION: the lamp is the important list
+    *important_hitables = new hitable_list(imp, 1);
+    *scene = new hitable_list(list, i);
+    // DECISION: the camera of the live cornell_box (src/scenes.h:194-197)
+    *cam = new camera(vec3(278.0f, 278.0f, -800.0f), vec3(278.0f, 278.0f, 278.0f), vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect, 0.0f,
+                      800.0f, 0.0f, 1.0f);
+}
+
+// src/scenes.h:35-85 -- "random spheres" (book 1 cover), n = 500: BASELINE.json config 1
+inline void random_spheres(hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    int n = 500;
+    int surf_radius = ((int)sqrtf((float)n)) / 2 - 1;
+    hitable **list = new hitable *[n + 3];
+    list[0] = new sphere(vec3(0, -1000, 0), 1000, new lambertian(new constant_texture(vec3(0.5f, 0.5f, 0.5f))));
+    int i = 1;
+    for (int a = -surf_radius; a < surf_radius; ++a) {
+        for (int b = -surf_radius; b < surf_radius; ++b) {
+            // one draw per statement: the reference's nested constructor calls leave the order to the compiler
+            float choose_mat = RAN01();
+            float cx = a + 0.9f * RAN01();
+            float cz = b + 0.9f * RAN01();
+            vec3 center(cx, 0.2f, cz);
+            if ((center - vec3(4.0f, 0.2f, 0.0f)).length() > 0.9f) {
+                if (choose_mat < 0.8f) {
+                    float lift = 0.5f * RAN01();
+                    float r0 = RAN01() * RAN01();
+                    float g0 = RAN01() * RAN01();
+                    float b0 = RAN01() * RAN01();
+                    list[i++] = new moving_sphere(center, center + vec3(0.0f, lift, 0.0f), 0.0f, 1.0f, 0.2f,
+                                                  new lambertian(new constant_texture(vec3(r0, g0, b0))));
+                } else if (choose_mat < 0.95f) {
+                    float r0 = 0.5f * (1.0f + RAN01());
+                    float g0 = 0.5f * (1.0f + RAN01());
+                    float b0 = 0.5f * (1.0f + RAN01());
+                    float fz = 0.5f * RAN01();
+                    list[i++] = new sphere(center, 0.2f, new metal(new constant_texture(vec3(r0, g0, b0)), fz));
+                } else {
+                    list[i++] = new sphere(center, 0.2f, new dielectric(1.5f));
+                }
+            }
+        }
+    }
+    list[i++] = new sphere(vec3(0.0f, 1.0f, 0.0f), 1.0f, new dielectric(1.5f));
+    list[i++] = new sphere(vec3(-4.0f, 1.0f, 0.0f), 1.0f, new lambertian(new constant_texture(vec3(0.4f, 0.2f, 0.1f))));
+    list[i++] = new sphere(vec3(4.0f, 1.0f, 0.0f), 1.0f, new metal(new constant_texture(vec3(0.7f, 0.6f, 0.5f)), 0.0f));
+    // DECISION: the old function has no emitter and a miss is black (src/main.cpp:125).  Light = one panel
+    // above the scene, in the style of the reference's rect lamps; it is the important list.
+    hitable *panel = new xz_rect(-6, 6, -6, 6, 12, new diffuse_light(new constant_texture(vec3(6, 6, 6))));
+    list[i++] = panel;
+    hitable **imp = new hitable *[1];
+    imp[0] = panel;
+    *important_hitables = new hitable_list(imp, 1);
+    *scene = new hitable_list(list, i);
+    // DECISION: the book's camera for this scene (the reference keeps none), aperture 0.1 so the lens is exercised
+    *cam = new camera(vec3(13.0f, 2.0f, 3.0f), vec3(0.0f, 0.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f), 20.0f, aspect, 0.1f, 10.0f, 0.0f,
+                      1.0f);
+}
+
+// src/scenes.h:234-314 -- "The Next Week" final scene: BASELINE.json config 3
+inline void next_week_final(hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    hitable **list = new hitable *[30];
+    hitable **boxlist = new hitable *[400];
+    hitable **boxlist2 = new hitable *[1000];
+    material *white = new lambertian(new constant_texture(vec3(0.73f, 0.73f, 0.73f)));
+    material *ground = new lambertian(new constant_texture(vec3(0.48f, 0.83f, 0.53f)));
+    int nb = 20, b = 0;
+    for (int i = 0; i < nb; ++i) {
+        for (int j = 0; j < nb; ++j) {
+            float w = 100.0f;
+            float x0 = -1000.0f + i * w, z0 = -1000.0f + j * w, y0 = 0.0f;
+            float x1 = x0 + w, y1 = 100.0f * (RAN01() + 0.01f), z1 = z0 + w;
+            boxlist[b++] = new box(vec3(x0, y0, z0), vec3(x1, y1, z1), ground);
+        }
+    }
+    int l = 0;
+    list[l++] = new bvh_node(boxlist, b, 0.0f, 1.0f);
+    material *light = new diffuse_light(new constant_texture(vec3(7, 7, 7)));
+    hitable *lamp = new xz_rect(123, 423, 147, 412, 554, light);
+    list[l++] = lamp;
+    vec3 center(400, 400, 200);
+    list[l++] = new moving_sphere(center, center + vec3(30, 0, 0), 0, 1, 50,
+                                  new lambertian(new constant_texture(vec3(0.7f, 0.3f, 0.1f))));
+    hitable *glass_ball = new sphere(vec3(260, 150, 45), 50, new dielectric(1.5f));
+    list[l++] = glass_ball;
+    list[l++] = new sphere(vec3(0, 150, 145), 50, new metal(new constant_texture(vec3(0.8f, 0.8f, 0.9f)), 10.0f));
+    hitable *boundary = new sphere(vec3(360, 150, 145), 70, new dielectric(1.5f));
+    list[l++] = boundary;
+    list[l++] = new constant_medium(boundary, 0.2f, new constant_texture(vec3(0.2f, 0.4f, 0.9f)));
+    boundary = new sphere(vec3(0, 0, 0), 5000, new dielectric(1.5f));
+    list[l++] = new constant_medium(boundary, 0.0001f, new constant_texture(vec3(1.0f, 1.0f, 1.0f)));
+    int nx = 0, ny = 0;
+    unsigned char *tex_data = rt_ext_earth_pixels(&nx, &ny);
+    if (tex_data) list[l++] = new sphere(vec3(400, 200, 400), 100, new lambertian(new image_texture(tex_data, nx, ny)));
+    list[l++] = new sphere(vec3(220, 280, 300), 80, new lambertian(new noise_texture(0.1f)));
+    int ns = 1000;
+    for (int j = 0; j < ns; ++j) {
+        float z = 165.0f * RAN01(), y = 165.0f * RAN01(), x = 165.0f * RAN01(); // last argument first, as g++ evaluates the original
+        boxlist2[j] = new sphere(vec3(x, y, z), 10, white);
+    }
+    list[l++] = new translate(new rotate_y(new bvh_node(boxlist2, ns, 0.0f, 1.0f), 15.0f), vec3(-100.0f, 270.0f, 395.0f));
+    hitable **imp = new hitable *[2];
+    imp[0] = lamp, imp[1] = glass_ball; // DECISION: lamp + glass ball, like the live cornell_box samples its lamp and its glass sphere
+    *important_hitables = new hitable_list(imp, 2);
+    *scene = new hitable_list(list, l);
+    // the camera the reference keeps in a comment for this scene (src/scenes.h:14)
+    *cam = new camera(vec3(350.0f, 278.0f, -450.0f), vec3(180.0f, 278.0f, 278.0f), vec3(0.0f, 1.0f, 0.0f), 45.0f, aspect, 0.0f,
+                      800.0f, 0.0f, 1.0f);
+}
+
+typedef void (*rt_ext_scene_fn)(hitable **, hitable **, camera **, float);
+inline rt_ext_scene_fn rt_extra_scene(const char *name)
+{
+    if (!strcmp(name, "cornell_box_volumes")) return cornell_box_volumes;
+    if (!strcmp(name, "random_spheres")) return random_spheres;
+    if (!strcmp(name, "next_week_final")) return next_week_final;
+    return nullptr;
+}
+
+#endif // RT_SCENES_EXT_H_
