@@ -75,6 +75,8 @@ __device__ __forceinline__ void flush_tile(const float *acc, int lane, int tile_
     }
 }
 
+// LANES: per-lane walk of the tree (world_hit_lanes) instead of the wave-uniform one (world_hit)
+template <bool LANES>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S, RenderArgs A, float *__restrict__ accum)
 {
     __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S
 
         // ---- 2. closest hit ------------------------------------------------------
         Hit h;
-        const bool hit_any = world_hit(S, r, 0.001f, RT_FLT_MAX, alive, rng, h);
+        const bool hit_any = LANES ? world_hit_lanes(S, r, 0.001f, RT_FLT_MAX, alive, rng, h)
+                                   : world_hit(S, r, 0.001f, RT_FLT_MAX, alive, rng, h);
 
         // ---- 3. shade -------------------------------------------------------------
         if (alive) {
@@ -171,6 +174,7 @@ __global__ void resolve_kernel(const float4 *__restrict__ accum, int n, uint32_t
     out[i] = 0xff000000u | (q[2] << 16) | (q[1] << 8) | q[0];
 }
 
+template <bool LANES>
 __global__ __launch_bounds__(256) void trace_kernel(DevScene S, int n, const float *__restrict__ rays, float t_min, float t_max,
                                                     uint32_t seed, rt_hit *__restrict__ out)
 {
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, int n, const flo
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
     Rng rng{rt_path_key(seed, (uint32_t)k, 0u)};
     Hit h;
-    bool any = world_hit(S, r, t_min, t_max, alive, rng, h);
+    bool any = LANES ? world_hit_lanes(S, r, t_min, t_max, alive, rng, h) : world_hit(S, r, t_min, t_max, alive, rng, h);
     if (!alive) return;
     rt_hit o;
     o.prim_id = any ? S.prims[h.prim].user_id : -1;
@@ -596,8 +600,10 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
         hipLaunchKernelGGL(render_fast_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
     else if (use_fast)
         hipLaunchKernelGGL(render_fast_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    else if (s->dev.n_entries > RT_UNIFORM_WALK_MAX)
+        hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
     else
-        hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
+        hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
     RT_HIP(hipGetLastError());
     s->last_render_path = use_fast ? RT_PATH_FAST : RT_PATH_EXACT;
     RT_HIP(hipEventRecord(s->ev1, stream));
@@ -689,8 +695,10 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
         if (s->trace_path == RT_PATH_FAST)
             hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
                                d_rays, t_min, t_max, d_hits);
+        else if (s->dev.n_entries > RT_UNIFORM_WALK_MAX)
+            hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
         else
-            hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
+            hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(h_hits, d_hits, sizeof(rt_hit) * N, hipMemcpyDeviceToHost);

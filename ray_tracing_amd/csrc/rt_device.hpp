@@ -394,6 +394,97 @@ RT_DEV bool world_hit(const DevScene &S, const Ray &wr, float t_min, float t_max
 }
 
 // ---------------------------------------------------------------------------
+// The same walk with a PER-LANE entry index, for scenes too large for the wave to
+// visit together (hundreds of entries and up: with incoherent rays the union of the
+// 64 lanes' subtrees is most of the tree).  Order, box tests, tie rule and the
+// order of constant_medium's draws are those of world_hit(); only the mapping to
+// the machine differs: each lane follows its own skip links and fetches its own
+// entries (two dwordx4 loads) and primitives.  No stack is needed because the
+// reference's order is fixed (left, right, both always; src/bvh.h:128-129).
+// Classic while-while shape: lanes first run down boxes until each stands on a
+// leaf, then the wave tests leaves together.
+// ---------------------------------------------------------------------------
+RT_DEV bool world_hit_lanes(const DevScene &S, const Ray &wr, float t_min, float t_max, bool alive, Rng &rng, Hit &best)
+{
+    bool any = false;
+    const int n = S.n_entries;
+    int i = alive ? 0 : n;
+    int cur_chain = 0;
+    Ray lr = wr;
+    V3 inv = v3(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+    best.t = 0.0f, best.u = best.v = 0.0f, best.p = best.n = v3(0, 0, 0), best.material = -1, best.prim = -1;
+
+    while (__any(i < n)) {
+        int leaf = -1;
+        while (i < n) { // boxes
+            const rt_entry e = S.entries[i];
+            if ((e.b & 255) != RT_ENTRY_INNER) {
+                leaf = e.a;
+                break;
+            }
+            const int chain = e.b >> 8;
+            if (chain != cur_chain) {
+                lr = chain_down(S, chain, wr);
+                inv = v3(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                cur_chain = chain;
+            }
+            i = slab_test(e.lo, e.hi, lr, inv, t_min, t_max) ? i + 1 : e.a;
+        }
+        if (leaf >= 0) {
+            const rt_prim &pr = S.prims[leaf];
+            if (pr.chain != cur_chain) {
+                lr = chain_down(S, pr.chain, wr);
+                inv = v3(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                cur_chain = pr.chain;
+            }
+            float t = 0.0f, u = 0.0f, v = 0.0f;
+            V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
+            int which = leaf, material;
+            bool h;
+            if (pr.kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53
+                const rt_prim &bp = S.prims[pr.first];
+                Ray br = bp.chain == cur_chain ? lr : chain_down(S, bp.chain, wr);
+                float t1 = 0.0f, t2 = 0.0f;
+                int dummy;
+                bool h1 = simple_hit(S, pr.first, bp, br, -RT_FLT_MAX, RT_FLT_MAX, true, false, t1, p, nn, u, v, dummy);
+                bool h2 = simple_hit(S, pr.first, bp, br, t1 + 0.0001f, RT_FLT_MAX, h1, false, t2, p, nn, u, v, dummy);
+                h = false;
+                if (h2) {
+                    if (t1 < t_min) t1 = t_min;
+                    if (t1 > t_max) t1 = t_max;
+                    if (!(t1 >= t2)) {
+                        if (t1 < 0) t1 = 0;
+                        float hit_distance = -(1.0f / pr.f[0]) * logf(rng.next());
+                        t = t1 + hit_distance / len(lr.d);
+                        p = at(lr, t);
+                        nn = v3(1, 0, 0);
+                        u = v = 0.0f;
+                        h = true;
+                    }
+                }
+                material = pr.material;
+            } else {
+                h = simple_hit(S, leaf, pr, lr, t_min, t_max, true, true, t, p, nn, u, v, which);
+                material = pr.material;
+                if (h && pr.kind == RT_PRIM_GROUP) material = S.prims[which].material;
+            }
+            if (h && (!any || !(best.t < t))) {
+                chain_up(S, cur_chain, p, nn);
+                best.t = t, best.u = u, best.v = v, best.p = p, best.n = nn;
+                best.prim = which;
+                best.material = material;
+                any = true;
+            }
+            ++i;
+        }
+    }
+    return any;
+}
+
+// Entry counts up to this use the wave-uniform walk, larger scenes the per-lane walk.
+#define RT_UNIFORM_WALK_MAX 64
+
+// ---------------------------------------------------------------------------
 // textures: src/texture.h, src/perlin.h
 // ---------------------------------------------------------------------------
 // the 256 gradient vectors perlin::noise indexes (src/perlin.h:114-115); see tools/gen_perlin_table.py
