@@ -1,0 +1,111 @@
+"""The command-line driver (ray_tracing_amd/cli/raytracer.cpp) against the reference executable's behaviour.
+
+CPU part: option parsing and console text equal the compiled reference's, word for word, on the command lines
+of tests/golden/cli_text.json (written by oracle/make_cli_golden.py from oracle/_ref/rt_ref); without a GPU the
+program fails loudly.  GPU part: the PNG files hold exactly the pixels rt_resolve gives through the C-ABI."""
+import json
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "ray_tracing_amd", "bin", "raytracer")
+CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "cli_text.json")))
+
+
+def run(args, cwd=None):
+    return subprocess.run([EXE] + list(args), capture_output=True, text=True, timeout=300, cwd=cwd)
+
+
+def read_png(path):
+    """Minimal decoder for 8-bit RGBA, non-interlaced PNG; returns uint32 [ny][nx] words 0xAABBGGRR."""
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, nx, ny = 8, b"", 0, 0
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + body) == crc, "bad chunk checksum"
+        if typ == b"IHDR":
+            nx, ny, depth, ctype, comp, flt, lace = struct.unpack(">IIBBBBB", body)
+            assert (depth, ctype, comp, flt, lace) == (8, 6, 0, 0, 0)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(ny, 4 * nx + 1)
+    assert not raw[:, 0].any(), "only filter 0 is written"
+    return np.ascontiguousarray(raw[:, 1:]).view("<u4").reshape(ny, nx)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[" ".join(c["args"]) for c in CASES])
+def test_console_text_equals_the_reference(case):
+    p = run(case["args"])
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == case["stdout"]
+
+
+def test_bad_command_lines_are_rejected():
+    for args in (["--no-such-option"], ["-q"], ["-w"], ["-w", "abc", "-x"], ["--path", "cpu", "-w", "4", "-h", "4"]):
+        p = run(args)
+        assert p.returncode != 0 and "raytracer:" in p.stderr, args
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_device_is_a_loud_failure(tmp_path):
+    p = run(["-w", "8", "-h", "8", "-s", "1", "-o", str(tmp_path / "o.png")])
+    assert p.returncode != 0 and "device" in p.stderr.lower()
+    assert not (tmp_path / "o.png").exists()
+
+
+@pytest.mark.gpu
+def test_png_pixels_equal_rt_resolve(tmp_path):
+    from ray_tracing_amd import api
+    from ray_tracing_amd.api import HostScene, Scene
+    nx, ny, ns = 96, 64, 6
+    out = tmp_path / "img.png"
+    p = run(["-w", str(nx), "-h", str(ny), "-s", str(ns), "-S", "2", "-r", "12", "--seed", "9", "-o", str(out), "-m", "-p"])
+    assert p.returncode == 0, p.stderr
+    assert "Single pass finished" in p.stdout and "Writing file." in p.stdout and f"{ns}/{ns} : 100.00%" in p.stdout
+    sc = Scene(HostScene("cornell_box", nx / ny), 0)
+    total = np.zeros((ny, nx, 4), np.float32)
+    for s in range(ns):
+        acc, rgba = api.render_to_host(sc, nx, ny, s, s + 1, sub_samples=2, max_depth=12, seed=9)
+        got = read_png(str(tmp_path / f"img_{s}.png"))
+        assert np.array_equal(got, rgba), f"sample {s}"
+        total += acc
+    # the final image: sums in sample order, then the reference's resolve (src/main.cpp:708-743)
+    import oracle_lib as O
+    got = read_png(str(out))
+    assert np.array_equal(got, np.asarray(O.resolve(total)).reshape(ny, nx))
+    c = np.sqrt(total[..., [3, 2, 1]] * np.float32(1.0 / ns), dtype=np.float32).clip(0, 1)
+    q = (c * np.float32(255.99)).astype(np.uint32)
+    assert np.array_equal(got, 0xFF000000 | (q[..., 2] << 16) | (q[..., 1] << 8) | q[..., 0])
+    # passes: primary hits at pixel centres
+    nrm = read_png(str(tmp_path / "img_NORMAL.png"))
+    dep = read_png(str(tmp_path / "img_DEPTH.png"))
+    assert (nrm >> 24 == 0xFF).all() and (dep >> 24 == 0xFF).all()
+    assert len(np.unique(nrm)) >= 5  # walls, floor, ceiling, box faces, sphere
+    assert (dep & 0xFF).max() == 255
+    assert os.path.exists(tmp_path / "img_UV.png")
+    sc.close()
+
+
+@pytest.mark.gpu
+def test_single_call_render_equals_the_api(tmp_path):
+    from ray_tracing_amd import api
+    from ray_tracing_amd.api import HostScene, Scene
+    nx, ny, ns = 64, 64, 16
+    out = tmp_path / "o.png"
+    p = run(["-w", str(nx), "-h", str(ny), "-s", str(ns), "-r", "50", "-o", str(out), "--scene", "cornell_box_volumes"])
+    assert p.returncode == 0, p.stderr
+    sc = Scene(HostScene("cornell_box_volumes", nx / ny), 0)
+    acc, rgba = api.render_to_host(sc, nx, ny, 0, ns, max_depth=50, seed=1)
+    got = read_png(str(out))
+    d = np.abs(got.view(np.uint8).astype(int) - rgba.view(np.uint8).astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01  # float atomics may reorder sums between two runs
+    sc.close()
