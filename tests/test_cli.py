@@ -17,6 +17,12 @@ EXE = os.path.join(ROOT, "ray_tracing_amd", "bin", "raytracer")
 CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "cli_text.json")))
 
 
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(EXE):  # normally built by __graft_entry__.build(); g++ only, seconds
+        subprocess.run(["make", "-C", os.path.join(ROOT, "ray_tracing_amd"), "bin/raytracer"], check=True)
+
+
 def run(args, cwd=None):
     return subprocess.run([EXE] + list(args), capture_output=True, text=True, timeout=300, cwd=cwd)
 
