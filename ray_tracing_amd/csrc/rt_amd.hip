@@ -220,7 +220,7 @@ __device__ __forceinline__ void load_records(const uint32_t *__restrict__ recs, 
     R.d[0] = a.x, R.d[1] = a.y, R.d[2] = a.z, R.d[3] = a.w, R.d[4] = b.x, R.d[5] = b.y, R.d[6] = b.z, R.d[7] = b.w;
 }
 
-template <bool TEX>
+template <bool TEX, bool FLAT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevScene S, const uint32_t *__restrict__ recs,
                                                                             rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
 {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
 
         float t;
         int rec;
-        rtf::scan(recs, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
+        rtf::scan<FLAT>(recs, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
         rtf::Surface sf;
         rtf::build_surface(R, Y, r, t, rec, sf); // every lane takes part in the cross-lane fetches
 
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
     float t;
     int rec;
-    rtf::scan(recs, Y, r, t_min, t_max, alive, t, rec);
+    rtf::scan<false>(recs, Y, r, t_min, t_max, alive, t, rec); // the general form also walks flat streams
     rtf::Surface sf;
     rtf::build_surface(R, Y, r, t, rec, sf);
     const uint32_t kw = rtf::sh_u(R.d[7], rec < 0 ? 0 : rec);
@@ -346,6 +346,7 @@ struct rt_scene {
     // register-resident form (rt_records.h), when the scene fits
     bool fast_ok = false;
     bool fast_textured = false; // some material's texture is not a constant
+    bool fast_flat = false;     // the record stream holds no box records
     const char *fast_why = "";
     rtf::Layout layout{0, 0, 0, 0};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids (inside blob)
@@ -526,6 +527,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     s->d_records = (uint32_t *)(b + parts[8].off);
     s->d_rec_user = (int32_t *)(b + parts[9].off);
     s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights};
+    s->fast_flat = fast_ok && tab.flat != 0;
     *out = s;
     return RT_OK;
 }
@@ -596,10 +598,17 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     if (A.atomic_out && !accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
     const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     RT_HIP(hipEventRecord(s->ev0, stream));
-    if (use_fast && s->fast_textured)
-        hipLaunchKernelGGL(render_fast_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
-    else if (use_fast)
-        hipLaunchKernelGGL(render_fast_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    if (use_fast) {
+        const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
+        if (s->fast_textured && s->fast_flat)
+            hipLaunchKernelGGL((render_fast_kernel<true, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+        else if (s->fast_textured)
+            hipLaunchKernelGGL((render_fast_kernel<true, false>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+        else if (s->fast_flat)
+            hipLaunchKernelGGL((render_fast_kernel<false, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+        else
+            hipLaunchKernelGGL((render_fast_kernel<false, false>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    }
     else if (s->dev.n_entries > RT_UNIFORM_WALK_MAX)
         hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
     else

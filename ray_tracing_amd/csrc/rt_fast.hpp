@@ -122,9 +122,11 @@ RTF_DEV void apply_chain(const uint32_t *__restrict__ recs, uint32_t chain_bits,
 // ---------------------------------------------------------------------------
 // world->hit(): bvh_node::hit (src/bvh.h:123-163) over the record stream.
 // Returns the closest t and the stream index of the record that was hit (-1: miss).
-// Lists (box faces) follow hitable_list::hit (src/hitable_list.h:18-34): the upper
-// bound shrinks from member to member, then the list's result competes like any leaf:
-// it replaces the best so far unless the best is strictly nearer (src/bvh.h:132-139).
+// Every primitive record competes with the best so far and replaces it unless the best is
+// strictly nearer (src/bvh.h:132-139).  Members of lists (box faces) are stored as leaves of
+// their own: for rects that is hitable_list::hit (rt_records.cpp explains why).
+// best_t starts at t_max, so `t <= best_t` is also the upper range test of the primitive.
+// FLAT: the stream holds no box records (small scenes), so no lane ever skips.
 // ---------------------------------------------------------------------------
 // One rect record against the ray of its chain.  Straight-line code per axis (the axis is
 // wave-uniform); bitwise & on purpose: && would make hipcc branch around every comparison.
@@ -136,10 +138,11 @@ RTF_DEV bool rect_in(const SRec &c, float ok, float ik, float oa, float da, floa
     return (t >= t_min) & (t <= bound) & (a >= sf(c, 0)) & (a <= sf(c, 1)) & (b >= sf(c, 2)) & (b <= sf(c, 3));
 }
 
+template <bool FLAT>
 RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray &wr, float t_min, float t_max,
                   bool alive, float &best_t, int &best_rec)
 {
-    best_t = __builtin_inff();
+    best_t = t_max;
     best_rec = -1;
     int resume = 0;
     uint32_t cur_chain = 0;
@@ -147,8 +150,6 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray 
     set_local(w, wr.o, wr.d);
     l = w;
     const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
-    float gt = t_max; // bound and winner inside the current list
-    int grec = -1;
 
     // A plain counted loop keeps i in an SGPR.  A lane that missed a box carries `resume`, the index
     // after that subtree; when every lane is skipping, a record costs one compare and one branch.
@@ -156,8 +157,11 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray 
     for (int i = 0; i < Y.n_stream; ++i) {
         const SRec c = nxt;
         nxt = load_rec(recs, i + 1); // the table is padded: record n_stream exists
-        const bool on = alive & (resume <= i);
-        if (__ballot(on) == 0ull) continue;
+        bool on = alive;
+        if (!FLAT) {
+            on = alive & (resume <= i);
+            if (__ballot(on) == 0ull) continue;
+        }
         const uint32_t kw = c.d[7];
         const uint32_t kind = kw & 15u;
         if (kind != RT_REC_SPHERE) {
@@ -168,7 +172,7 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray 
                 cur_chain = chain;
             }
         }
-        if (kind == RT_REC_INNER) { // aabb::hit, src/aabb.h:60-83
+        if (!FLAT && kind == RT_REC_INNER) { // aabb::hit, src/aabb.h:60-83
             const float x0 = (sf(c, 0) - l.o.x) * l.inv.x, x1 = (sf(c, 4) - l.o.x) * l.inv.x;
             const float y0 = (sf(c, 1) - l.o.y) * l.inv.y, y1 = (sf(c, 5) - l.o.y) * l.inv.y;
             const float z0 = (sf(c, 2) - l.o.z) * l.inv.z, z1 = (sf(c, 6) - l.o.z) * l.inv.z;
@@ -178,16 +182,14 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray 
             resume = (on & !(tf > tn)) ? skip : resume;
             continue;
         }
-        const bool single = (kw & (RT_KW_FIRST | RT_KW_LAST)) == (RT_KW_FIRST | RT_KW_LAST);
-        const float bound = (kw & RT_KW_FIRST) ? t_max : gt;
         float t;
         bool in;
         if (kind == RT_REC_RECT) { // src/plane.h:9-29, 47-67, 109-129
             const uint32_t axis = (kw >> RT_KW_AXIS_SHIFT) & 3u;
-            if (axis == 0) in = rect_in(c, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, t_min, bound, t);
-            else if (axis == 1) in = rect_in(c, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, t_min, bound, t);
-            else in = rect_in(c, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, t_min, bound, t);
-        } else { // sphere, world space: src/sphere.h:21-59
+            if (axis == 0) in = rect_in(c, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, t_min, best_t, t);
+            else if (axis == 1) in = rect_in(c, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, t_min, best_t, t);
+            else in = rect_in(c, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, t_min, best_t, t);
+        } else { // sphere, world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree
             const V3 oc = v3(wr.o.x - sf(c, 0), wr.o.y - sf(c, 1), wr.o.z - sf(c, 2));
             const float radius = sf(c, 3);
             const float b = fdot(oc, wr.d);
@@ -195,25 +197,13 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray 
             const float disc = fmaf(b, b, -(w_dd * cc));
             const float sq = fsqrt(disc);
             const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
-            const bool in1 = (t1 < bound) & (t1 > t_min), in2 = (t2 < bound) & (t2 > t_min);
-            in = (disc > 0.0f) & (in1 | in2);
+            const bool in1 = (t1 < t_max) & (t1 > t_min), in2 = (t2 < t_max) & (t2 > t_min);
             t = in1 ? t1 : t2;
+            in = (disc > 0.0f) & (in1 | in2) & (t <= best_t);
         }
-        in = in & on;
-        if (single) { // a leaf of its own: competes directly (src/bvh.h:130-151)
-            const bool take = in & (t <= best_t);
-            best_t = take ? t : best_t;
-            best_rec = take ? i : best_rec;
-        } else { // member of a list: hitable_list::hit, src/hitable_list.h:18-34
-            grec = (kw & RT_KW_FIRST) ? -1 : grec;
-            gt = in ? t : bound;
-            grec = in ? i : grec;
-            if (kw & RT_KW_LAST) {
-                const bool take = (grec >= 0) & (gt <= best_t);
-                best_t = take ? gt : best_t;
-                best_rec = take ? grec : best_rec;
-            }
-        }
+        const bool take = in & on;
+        best_t = take ? t : best_t;
+        best_rec = take ? i : best_rec;
     }
 }
 

@@ -89,6 +89,10 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
                 const rt_prim &c = d->prims[p.first + k];
                 if (!plain_static(c.kind)) { *why = "a list member is not a static sphere or rect"; return 0; }
                 if (c.flags & RT_PRIM_NEEDS_UV) { *why = "a texture reads (u,v)"; return 0; }
+                // Members of a list compete in the scan like leaves of their own (see emit below).  That equals
+                // hitable_list::hit for rects, whose test accepts t == closest_so_far (src/plane.h:13); a sphere's
+                // test is strict (src/sphere.h:31), so a list that holds one is left to the generic path.
+                if (c.kind == RT_PRIM_SPHERE && p.count > 1) { *why = "a list holds a sphere"; return 0; }
                 if (c.kind != RT_PRIM_SPHERE) use_chain(p.chain);
             }
             n_stream += p.count;
@@ -162,6 +166,7 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
     }
     out->n_records = at;
     out->n_stream = n_stream;
+    out->flat = keep_inner ? 0 : 1;
 
     // ---- the traversal stream ------------------------------------------------------------
     auto emit_prim = [&](int s, int prim_index, const rt_prim &p, int chain, uint32_t list_bits) {
@@ -202,9 +207,13 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
         }
         const rt_prim &p = d->prims[en.a];
         if (p.kind == RT_PRIM_GROUP) {
+            // hitable_list::hit (src/hitable_list.h:18-34) keeps the nearest member, the later one on a tie, and
+            // bvh_node::hit lets that result replace the best so far unless the best is strictly nearer
+            // (src/bvh.h:132-139).  Letting every member compete with the best so far under the same rule
+            // (t <= best) ends with the same (t, member): the minimum, latest on ties.  So members are emitted
+            // as leaves of their own and the scan needs no list state.
             for (int k = 0; k < p.count; ++k)
-                emit_prim(s + k, p.first + k, d->prims[p.first + k], p.chain,
-                          (k == 0 ? RT_KW_FIRST : 0u) | (k == p.count - 1 ? RT_KW_LAST : 0u));
+                emit_prim(s + k, p.first + k, d->prims[p.first + k], p.chain, RT_KW_FIRST | RT_KW_LAST);
         } else {
             emit_prim(s, en.a, p, p.chain, RT_KW_FIRST | RT_KW_LAST);
         }

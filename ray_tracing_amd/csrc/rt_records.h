@@ -58,6 +58,7 @@ typedef struct rt_record_table {
     int32_t materials_base;
     int32_t lights_base, n_lights;
     int32_t n_records;
+    int32_t flat;                /* 1: the stream holds no inner (box) records */
 } rt_record_table;
 
 #ifdef __cplusplus
