@@ -31,6 +31,7 @@
 #include "rt_device.hpp"
 #include "rt_error.h"
 #include "rt_fast.hpp"
+#include "rt_order.h"
 #include "rt_records.h"
 
 using namespace rt;
@@ -75,7 +76,31 @@ __device__ __forceinline__ void flush_tile(const float *acc, int lane, int tile_
     }
 }
 
-// LANES: per-lane walk of the tree (world_hit_lanes) instead of the wave-uniform one (world_hit)
+// The per-lane stacks of world_hit_ordered: [level][lane] per wave, 8 KiB per wave, only in the kernels that walk per lane.
+template <bool LANES>
+struct LaneStacks {
+    static __device__ __forceinline__ int *get(int, int) { return nullptr; }
+};
+template <>
+struct LaneStacks<true> {
+    static __device__ __forceinline__ int *get(int wave, int lane)
+    {
+        __shared__ int stacks[WAVES_PER_BLOCK][RT_ORD_MAX_DEPTH * 64];
+        return &stacks[wave][lane];
+    }
+};
+// closest hit for the kernels below: the wave-uniform walk for small scenes; per lane for large ones, ordered and
+// culled when the entries are a binary tree (always, for trees the flattener wrote), else in the reference's order
+template <bool LANES>
+__device__ __forceinline__ bool closest_hit(const DevScene &S, const Ray &r, float t_min, float t_max, bool alive, Rng &rng, Hit &h,
+                                            int *stack)
+{
+    if (!LANES) return world_hit(S, r, t_min, t_max, alive, rng, h);
+    if (S.ordered) return world_hit_ordered(S, r, t_min, t_max, alive, rng, h, stack);
+    return world_hit_lanes(S, r, t_min, t_max, alive, rng, h);
+}
+
+// LANES: per-lane walk of the tree instead of the wave-uniform one (world_hit)
 template <bool LANES>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S, RenderArgs A, float *__restrict__ accum)
 {
@@ -94,6 +119,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S
 
     float *acc = tile_acc[wave];
     acc[lane] = 0.0f, acc[64 + lane] = 0.0f, acc[128 + lane] = 0.0f;
+    int *stack = LaneStacks<LANES>::get(wave, lane);
 
     int next = 0; // wave-uniform pool cursor
     bool alive = false;
@@ -137,8 +163,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S
 
         // ---- 2. closest hit ------------------------------------------------------
         Hit h;
-        const bool hit_any = LANES ? world_hit_lanes(S, r, 0.001f, RT_FLT_MAX, alive, rng, h)
-                                   : world_hit(S, r, 0.001f, RT_FLT_MAX, alive, rng, h);
+        const bool hit_any = closest_hit<LANES>(S, r, 0.001f, RT_FLT_MAX, alive, rng, h, stack);
 
         // ---- 3. shade -------------------------------------------------------------
         if (alive) {
@@ -185,7 +210,9 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, int n, const flo
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
     Rng rng{rt_path_key(seed, (uint32_t)k, 0u)};
     Hit h;
-    bool any = LANES ? world_hit_lanes(S, r, t_min, t_max, alive, rng, h) : world_hit(S, r, t_min, t_max, alive, rng, h);
+    static_assert(WAVES_PER_BLOCK * 64 == 256, "trace_kernel is launched with 256 threads");
+    int *stack = LaneStacks<LANES>::get(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+    bool any = closest_hit<LANES>(S, r, t_min, t_max, alive, rng, h, stack);
     if (!alive) return;
     rt_hit o;
     o.prim_id = any ? S.prims[h.prim].user_id : -1;
@@ -471,7 +498,10 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     rt_record_table tab;
     const char *why = "";
     const bool fast_ok = rt_records_build(d, &tab, &why) != 0;
-    part parts[10] = {
+    std::vector<int32_t> order;
+    int tree_depth = 0;
+    const bool ordered = rt_order_build(d, order, &tree_depth);
+    part parts[11] = {
         {d->entries, sizeof(rt_entry) * (size_t)d->n_entries, 0},
         {d->prims, sizeof(rt_prim) * (size_t)d->n_prims, 0},
         {d->xforms, sizeof(rt_xform) * (size_t)d->n_xforms, 0},
@@ -482,6 +512,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         {d->lights, sizeof(int32_t) * (size_t)d->n_lights, 0},
         {tab.rec, sizeof tab.rec, 0},
         {tab.user_id, sizeof tab.user_id, 0},
+        {order.data(), sizeof(int32_t) * order.size(), 0},
     };
     size_t total = 0;
     for (part &p : parts) {
@@ -519,6 +550,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     D.textures = (const rt_texture *)(b + parts[5].off);
     D.texels = (const uint8_t *)(b + parts[6].off);
     D.lights = (const int32_t *)(b + parts[7].off);
+    D.ord = (const int2 *)(b + parts[10].off);
+    D.ordered = ordered ? 1 : 0;
     D.n_entries = d->n_entries, D.n_lights = d->n_lights;
     D.cam = d->camera;
     s->fast_ok = fast_ok, s->fast_why = why;

@@ -24,6 +24,7 @@
 
 #include "../../include/rt_amd.h"
 #include "../../include/rt_rng.h"
+#include "rt_order.h"
 
 #define RT_PI 3.14159f           // src/main.cpp:54-56
 #define RT_M_PI 3.14159265358979323846f // (float)M_PI, used only by get_sphere_uv (src/utils.h:61-66)
@@ -98,7 +99,9 @@ struct DevScene {
     const rt_texture *textures;
     const uint8_t *texels;
     const int32_t *lights;
+    const int2 *ord; // rt_order.h: per inner entry {right child, flags}; only read when ordered != 0
     int32_t n_entries, n_lights;
+    int32_t ordered; // the entries are a binary tree no deeper than RT_ORD_MAX_DEPTH: world_hit_ordered may be used
     rt_camera cam;
 };
 
@@ -139,6 +142,35 @@ RT_DEV bool slab_test(const float *lo, const float *hi, const Ray &r, V3 inv, fl
         t_max = b < t_max ? b : t_max;
         ok = ok && !(t_max <= t_min);
     }
+    return ok;
+}
+
+// The same test, also returning the entry distance it ended with (>= the t_min passed in).
+RT_DEV bool slab_test_entry(const float *lo, const float *hi, const Ray &r, V3 inv, float t_min, float t_max, float &entry)
+{
+    bool ok = true;
+    {
+        float t0 = (lo[0] - r.o.x) * inv.x, t1 = (hi[0] - r.o.x) * inv.x;
+        float a = inv.x < 0.0f ? t1 : t0, b = inv.x < 0.0f ? t0 : t1;
+        t_min = a > t_min ? a : t_min;
+        t_max = b < t_max ? b : t_max;
+        ok = ok && !(t_max <= t_min);
+    }
+    {
+        float t0 = (lo[1] - r.o.y) * inv.y, t1 = (hi[1] - r.o.y) * inv.y;
+        float a = inv.y < 0.0f ? t1 : t0, b = inv.y < 0.0f ? t0 : t1;
+        t_min = a > t_min ? a : t_min;
+        t_max = b < t_max ? b : t_max;
+        ok = ok && !(t_max <= t_min);
+    }
+    {
+        float t0 = (lo[2] - r.o.z) * inv.z, t1 = (hi[2] - r.o.z) * inv.z;
+        float a = inv.z < 0.0f ? t1 : t0, b = inv.z < 0.0f ? t0 : t1;
+        t_min = a > t_min ? a : t_min;
+        t_max = b < t_max ? b : t_max;
+        ok = ok && !(t_max <= t_min);
+    }
+    entry = t_min;
     return ok;
 }
 
@@ -393,6 +425,49 @@ RT_DEV bool world_hit(const DevScene &S, const Ray &wr, float t_min, float t_max
     return any;
 }
 
+// One leaf of the tree for ONE lane (per-lane walks): the primitive `leaf` against the lane's ray.
+// Keeps (lr, inv, cur_chain), the ray in the space of the last chain visited.  Returns the hit in local
+// coordinates of cur_chain; the caller applies chain_up if it keeps the hit.
+RT_DEV bool leaf_hit_lane(const DevScene &S, int leaf, const Ray &wr, Ray &lr, V3 &inv, int &cur_chain, float t_min, float t_max,
+                          Rng &rng, float &t, float &u, float &v, V3 &p, V3 &nn, int &which, int &material)
+{
+    const rt_prim &pr = S.prims[leaf];
+    if (pr.chain != cur_chain) {
+        lr = chain_down(S, pr.chain, wr);
+        inv = v3(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+        cur_chain = pr.chain;
+    }
+    bool h;
+    if (pr.kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53
+        const rt_prim &bp = S.prims[pr.first];
+        Ray br = bp.chain == cur_chain ? lr : chain_down(S, bp.chain, wr);
+        float t1 = 0.0f, t2 = 0.0f;
+        int dummy;
+        bool h1 = simple_hit(S, pr.first, bp, br, -RT_FLT_MAX, RT_FLT_MAX, true, false, t1, p, nn, u, v, dummy);
+        bool h2 = simple_hit(S, pr.first, bp, br, t1 + 0.0001f, RT_FLT_MAX, h1, false, t2, p, nn, u, v, dummy);
+        h = false;
+        if (h2) {
+            if (t1 < t_min) t1 = t_min;
+            if (t1 > t_max) t1 = t_max;
+            if (!(t1 >= t2)) {
+                if (t1 < 0) t1 = 0;
+                float hit_distance = -(1.0f / pr.f[0]) * logf(rng.next());
+                t = t1 + hit_distance / len(lr.d);
+                p = at(lr, t);
+                nn = v3(1, 0, 0);
+                u = v = 0.0f;
+                h = true;
+            }
+        }
+        material = pr.material;
+    } else {
+        h = simple_hit(S, leaf, pr, lr, t_min, t_max, true, true, t, p, nn, u, v, which);
+        material = pr.material;
+        if (h && pr.kind == RT_PRIM_GROUP) material = S.prims[which].material;
+    }
+    return h;
+}
+
 // ---------------------------------------------------------------------------
 // The same walk with a PER-LANE entry index, for scenes too large for the wave to
 // visit together (hundreds of entries and up: with incoherent rays the union of the
@@ -431,43 +506,10 @@ RT_DEV bool world_hit_lanes(const DevScene &S, const Ray &wr, float t_min, float
             i = slab_test(e.lo, e.hi, lr, inv, t_min, t_max) ? i + 1 : e.a;
         }
         if (leaf >= 0) {
-            const rt_prim &pr = S.prims[leaf];
-            if (pr.chain != cur_chain) {
-                lr = chain_down(S, pr.chain, wr);
-                inv = v3(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
-                cur_chain = pr.chain;
-            }
             float t = 0.0f, u = 0.0f, v = 0.0f;
             V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
             int which = leaf, material;
-            bool h;
-            if (pr.kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53
-                const rt_prim &bp = S.prims[pr.first];
-                Ray br = bp.chain == cur_chain ? lr : chain_down(S, bp.chain, wr);
-                float t1 = 0.0f, t2 = 0.0f;
-                int dummy;
-                bool h1 = simple_hit(S, pr.first, bp, br, -RT_FLT_MAX, RT_FLT_MAX, true, false, t1, p, nn, u, v, dummy);
-                bool h2 = simple_hit(S, pr.first, bp, br, t1 + 0.0001f, RT_FLT_MAX, h1, false, t2, p, nn, u, v, dummy);
-                h = false;
-                if (h2) {
-                    if (t1 < t_min) t1 = t_min;
-                    if (t1 > t_max) t1 = t_max;
-                    if (!(t1 >= t2)) {
-                        if (t1 < 0) t1 = 0;
-                        float hit_distance = -(1.0f / pr.f[0]) * logf(rng.next());
-                        t = t1 + hit_distance / len(lr.d);
-                        p = at(lr, t);
-                        nn = v3(1, 0, 0);
-                        u = v = 0.0f;
-                        h = true;
-                    }
-                }
-                material = pr.material;
-            } else {
-                h = simple_hit(S, leaf, pr, lr, t_min, t_max, true, true, t, p, nn, u, v, which);
-                material = pr.material;
-                if (h && pr.kind == RT_PRIM_GROUP) material = S.prims[which].material;
-            }
+            const bool h = leaf_hit_lane(S, leaf, wr, lr, inv, cur_chain, t_min, t_max, rng, t, u, v, p, nn, which, material);
             if (h && (!any || !(best.t < t))) {
                 chain_up(S, cur_chain, p, nn);
                 best.t = t, best.u = u, best.v = v, best.p = p, best.n = nn;
@@ -476,6 +518,92 @@ RT_DEV bool world_hit_lanes(const DevScene &S, const Ray &wr, float t_min, float
                 any = true;
             }
             ++i;
+        }
+    }
+    return any;
+}
+
+// ---------------------------------------------------------------------------
+// The per-lane walk, ORDERED and CULLED, with the reference's results.
+//
+// bvh_node::hit visits both children with the same t_max and keeps the nearer hit, the right one on a tie
+// (src/bvh.h:128-151).  The winner of the whole tree is therefore the hit with the smallest t and, among
+// equal t, the one latest in depth-first order -- a rule that does not depend on the order of the visits.
+// So a lane may (a) visit the nearer child first, (b) skip a subtree whose box the ray enters behind the
+// best hit so far, and still end with the reference's hit, bit for bit:
+//   * a box is entered iff the reference's aabb::hit accepts it (same arithmetic, slab_test_entry) AND its
+//     entry distance is not beyond best.t by more than a margin.  Box and rect distances carry a few ulps of
+//     relative error; a sphere's t can be off by ~sqrt(eps) of the sphere's distance for grazing hits, so
+//     the margin is 2^-9 of (best.t + the box's largest side / |d|).  A skipped box cannot hold a winner.
+//   * primitives see the reference's t_min, t_max (not best.t): which hits exist is unchanged;
+//   * ties go to the larger entry index (= later in depth-first order);
+//   * subtrees that hold a constant_medium are walked left to right and never skipped: the medium draws a
+//     random number per visit (src/volume.h:43) and those draws must happen in the reference's order.
+// (A hit whose t is NaN -- a ray lying exactly in a rect's plane -- is ordered by the reference through
+// `!(best.t < t)`; here it never replaces a hit.  It needs an exactly zero direction component and an
+// origin exactly on the plane.)
+// Pending far children live in a per-lane stack in LDS: stack[level * 64], at most RT_ORD_MAX_DEPTH levels
+// (rt_order.cpp checks the depth of the tree on the host).
+// ---------------------------------------------------------------------------
+RT_DEV bool world_hit_ordered(const DevScene &S, const Ray &wr, float t_min, float t_max, bool alive, Rng &rng, Hit &best,
+                              int *stack)
+{
+    bool any = false;
+    int best_ord = -1;
+    int sp = 0;
+    int cur = alive ? 0 : -1;
+    int cur_chain = 0;
+    Ray lr = wr;
+    V3 inv = v3(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+    const float inv_len = 1.0f / len(wr.d); // chains are rigid: |d| is the same in every space
+    best.t = 0.0f, best.u = best.v = 0.0f, best.p = best.n = v3(0, 0, 0), best.material = -1, best.prim = -1;
+
+    while (__any(cur >= 0)) {
+        int leaf = -1, leaf_ord = -1;
+        while (cur >= 0) { // boxes
+            const rt_entry e = S.entries[cur];
+            if ((e.b & 255) != RT_ENTRY_INNER) {
+                leaf = e.a, leaf_ord = cur;
+                break;
+            }
+            const int chain = e.b >> 8;
+            if (chain != cur_chain) {
+                lr = chain_down(S, chain, wr);
+                inv = v3(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                cur_chain = chain;
+            }
+            const int2 o = S.ord[cur];
+            float entry;
+            bool in = slab_test_entry(e.lo, e.hi, lr, inv, t_min, t_max, entry);
+            if (any && !(o.y & RT_ORD_HAS_MEDIUM)) {
+                const float side = fmaxf(fmaxf(e.hi[0] - e.lo[0], e.hi[1] - e.lo[1]), e.hi[2] - e.lo[2]);
+                in = in && !(entry > best.t + 0.001953125f * (best.t + side * inv_len));
+            }
+            if (!in) {
+                cur = sp > 0 ? stack[--sp * 64] : -1;
+                continue;
+            }
+            const int axis = o.y & RT_ORD_AXIS_MASK;
+            const float da = axis == 0 ? lr.d.x : axis == 1 ? lr.d.y : lr.d.z;
+            const bool left_first =
+                (o.y & (RT_ORD_HAS_MEDIUM | RT_ORD_NO_PREFERENCE)) != 0 || ((da >= 0.0f) == ((o.y & RT_ORD_LEFT_LOWER) != 0));
+            stack[sp++ * 64] = left_first ? o.x : cur + 1;
+            cur = left_first ? cur + 1 : o.x;
+        }
+        if (leaf >= 0) {
+            float t = 0.0f, u = 0.0f, v = 0.0f;
+            V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
+            int which = leaf, material;
+            const bool h = leaf_hit_lane(S, leaf, wr, lr, inv, cur_chain, t_min, t_max, rng, t, u, v, p, nn, which, material);
+            if (h && (!any || t < best.t || (t == best.t && leaf_ord > best_ord))) {
+                chain_up(S, cur_chain, p, nn);
+                best.t = t, best.u = u, best.v = v, best.p = p, best.n = nn;
+                best.prim = which;
+                best.material = material;
+                best_ord = leaf_ord;
+                any = true;
+            }
+            cur = sp > 0 ? stack[--sp * 64] : -1;
         }
     }
     return any;
