@@ -31,6 +31,7 @@
 #include "rt_device.hpp"
 #include "rt_error.h"
 #include "rt_fast.hpp"
+#include "rt_fastlanes.hpp"
 #include "rt_order.h"
 #include "rt_records.h"
 
@@ -359,6 +360,118 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
     out[i] = o;
 }
 
+// ---------------------------------------------------------------------------
+// The same loop for scenes that do not fit the record table: every lane walks the tree on its own
+// (rt_fastlanes.hpp).  `recs` holds only the light records.
+// ---------------------------------------------------------------------------
+template <bool TEX>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
+                                                                                 rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
+{
+    __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (task >= A.n_tasks) return;
+
+    const int tile = task / A.n_chunks, chunk = task - tile * A.n_chunks;
+    const int tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
+    const int s0 = chunk * A.chunk_samples;
+    const int s1 = min(s0 + A.chunk_samples, A.n_samples);
+    const int total = 64 * (s1 - s0) * A.sub_samples;
+    const float inv_nx = 1.0f / float(A.nx), inv_ny = 1.0f / float(A.ny);
+
+    float *acc = tile_acc[wave];
+    acc[lane] = 0.0f, acc[64 + lane] = 0.0f, acc[128 + lane] = 0.0f;
+    __shared__ int bvh_stacks[WAVES_PER_BLOCK][RT_BVH_MAX_DEPTH * 64];
+    int *stack = &bvh_stacks[wave][lane];
+
+    int next = 0;
+    bool alive = false;
+    Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
+    V3 T = v3(1, 1, 1);
+    Rng rng{0u};
+    int depth = 0, pix = lane;
+
+    for (;;) {
+        const unsigned long long dead = __ballot(!alive);
+        if (dead != 0ull && next < total) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+            const int item = next + rank;
+            if (!alive && item < total) {
+                pix = item & 63;
+                const int q = item >> 6;
+                const int qs = A.sub_samples == 1 ? q : q / A.sub_samples;
+                const int sample = A.sample_begin + s0 + qs;
+                const int sub = q - qs * A.sub_samples;
+                const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
+                if (col < A.nx && row < A.ny) {
+                    rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
+                    const int j = A.ny - 1 - row;
+                    const float u = (float(col) + rng.next()) * inv_nx;
+                    const float v = (float(j) + rng.next()) * inv_ny;
+                    const V3 disk = S.cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
+                    const float time01 = rng.next();
+                    r = rtf::camera_ray(S.cam, u, v, disk, time01);
+                    T = v3(1, 1, 1);
+                    depth = 0;
+                    alive = true;
+                }
+            }
+            next += __popcll(dead);
+        }
+        if (!__any(alive)) {
+            if (next >= total) break;
+            continue;
+        }
+
+        float t;
+        int prim;
+        const bool hit_any = rtf::hit_bvh(S, r, 0.001f, RT_FLT_MAX, alive, rng, t, prim, stack);
+        if (alive) {
+            rtf::Surface sf;
+            if (hit_any) rtf::build_surface_lanes(S, r, t, prim, sf);
+            V3 L;
+            if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
+                alive = false;
+                if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
+                if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
+                if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[128 + pix], L.z);
+            }
+        }
+    }
+
+    flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
+}
+
+__global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n, const float *__restrict__ rays, float t_min, float t_max,
+                                                              uint32_t seed, rt_hit *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool alive = i < n;
+    const int k = alive ? i : 0;
+    const float *f = rays + 7 * (size_t)k;
+    Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
+    Rng rng{rt_path_key(seed, (uint32_t)k, 0u)};
+    __shared__ int bvh_stacks[4][RT_BVH_MAX_DEPTH * 64];
+    int *stack = &bvh_stacks[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][threadIdx.x & 63];
+    float t;
+    int prim;
+    const bool any = rtf::hit_bvh(S, r, t_min, t_max, alive, rng, t, prim, stack);
+    if (!alive) return;
+    rtf::Surface sf;
+    sf.p = sf.n = v3(0, 0, 0), sf.u = sf.v = 0.0f;
+    if (any) rtf::build_surface_lanes(S, r, t, prim, sf);
+    rt_hit o;
+    o.prim_id = any ? S.prims[prim].user_id : -1;
+    o.material = any ? S.prims[prim].material : -1;
+    o.t = any ? t : 0.0f, o.u = sf.u, o.v = sf.v;
+    o.p[0] = sf.p.x, o.p[1] = sf.p.y, o.p[2] = sf.p.z;
+    o.normal[0] = sf.n.x, o.normal[1] = sf.n.y, o.normal[2] = sf.n.z;
+    o.reserved = 0.0f;
+    out[i] = o;
+}
+
 } // namespace
 
 // ===========================================================================
@@ -374,6 +487,7 @@ struct rt_scene {
     bool fast_ok = false;
     bool fast_textured = false; // some material's texture is not a constant
     bool fast_flat = false;     // the record stream holds no box records
+    bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     const char *fast_why = "";
     rtf::Layout layout{0, 0, 0, 0};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids (inside blob)
@@ -501,7 +615,12 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     std::vector<int32_t> order;
     int tree_depth = 0;
     const bool ordered = rt_order_build(d, order, &tree_depth);
-    part parts[11] = {
+    // no record table: the per-lane fast path, with its own tree (rt_bvh.h) and the light records only
+    std::vector<rt_bvh_node> bvh;
+    int bvh_depth = 0;
+    const bool lanes_ok = !fast_ok && rt_bvh_build(d, bvh, &bvh_depth) && rt_records_build_lights(d, &tab) != 0;
+    if (!lanes_ok) bvh.clear();
+    part parts[12] = {
         {d->entries, sizeof(rt_entry) * (size_t)d->n_entries, 0},
         {d->prims, sizeof(rt_prim) * (size_t)d->n_prims, 0},
         {d->xforms, sizeof(rt_xform) * (size_t)d->n_xforms, 0},
@@ -513,6 +632,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         {tab.rec, sizeof tab.rec, 0},
         {tab.user_id, sizeof tab.user_id, 0},
         {order.data(), sizeof(int32_t) * order.size(), 0},
+        {bvh.data(), sizeof(rt_bvh_node) * bvh.size(), 0},
     };
     size_t total = 0;
     for (part &p : parts) {
@@ -551,12 +671,16 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     D.texels = (const uint8_t *)(b + parts[6].off);
     D.lights = (const int32_t *)(b + parts[7].off);
     D.ord = (const int2 *)(b + parts[10].off);
+    D.bvh = lanes_ok ? (const rt_bvh_node *)(b + parts[11].off) : nullptr;
     D.ordered = ordered ? 1 : 0;
     D.n_entries = d->n_entries, D.n_lights = d->n_lights;
     D.cam = d->camera;
     s->fast_ok = fast_ok, s->fast_why = why;
     for (int m = 0; fast_ok && m < d->n_materials; ++m)
         s->fast_textured |= (int32_t)tab.rec[tab.materials_base + m][1] >= 0;
+    s->lanes_ok = lanes_ok;
+    for (int m = 0; lanes_ok && m < d->n_materials; ++m)
+        s->fast_textured |= d->materials[m].texture >= 0 && d->textures[d->materials[m].texture].kind != RT_TEX_CONSTANT;
     s->d_records = (uint32_t *)(b + parts[8].off);
     s->d_rec_user = (int32_t *)(b + parts[9].off);
     s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights};
@@ -593,9 +717,11 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     int st = check_params(p, "rt_render");
     if (st != RT_OK) return st;
     hipStream_t stream = (hipStream_t)stream_;
-    if (s->render_path == RT_PATH_FAST && !s->fast_ok)
-        return rt_fail(RT_ERR_UNSUPPORTED, "rt_render: the register-resident path was requested but the scene does not fit it: %s", s->fast_why);
-    const bool use_fast = s->fast_ok && s->render_path != RT_PATH_EXACT;
+    if (s->render_path == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
+        return rt_fail(RT_ERR_UNSUPPORTED, "rt_render: the fast path was requested but cannot run this scene (%s; and no ordered walk)", s->fast_why);
+    // AUTO: the record table when the scene fits; the per-lane fast path for large trees; small scenes that do not fit
+    // the table (media, moving spheres) stay on the wave-uniform exact walk, which beats a per-lane walk of a tiny tree
+    const bool use_fast = s->render_path == RT_PATH_FAST || (s->render_path == RT_PATH_AUTO && (s->fast_ok || (s->lanes_ok && s->dev.n_entries > RT_UNIFORM_WALK_MAX)));
     RT_HIP(hipSetDevice(s->device));
     const size_t bytes = sizeof(float) * 4 * (size_t)p->nx * p->ny;
     const bool accumulate = (p->flags & RT_RENDER_ACCUMULATE) != 0;
@@ -631,7 +757,13 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     if (A.atomic_out && !accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
     const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     RT_HIP(hipEventRecord(s->ev0, stream));
-    if (use_fast) {
+    if (use_fast && s->lanes_ok) {
+        const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
+        if (s->fast_textured)
+            hipLaunchKernelGGL(render_fastlanes_kernel<true>, g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+        else
+            hipLaunchKernelGGL(render_fastlanes_kernel<false>, g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    } else if (use_fast) {
         const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
         if (s->fast_textured && s->fast_flat)
             hipLaunchKernelGGL((render_fast_kernel<true, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
@@ -724,8 +856,8 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
 {
     if (!s || n < 0 || (n > 0 && (!h_rays || !h_hits))) return rt_fail(RT_ERR_INVALID, "rt_trace_rays: bad argument");
     if (n == 0) return RT_OK;
-    if (s->trace_path == RT_PATH_FAST && !s->fast_ok)
-        return rt_fail(RT_ERR_UNSUPPORTED, "rt_trace_rays: the register-resident path was requested but the scene does not fit it: %s", s->fast_why);
+    if (s->trace_path == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
+        return rt_fail(RT_ERR_UNSUPPORTED, "rt_trace_rays: the fast path was requested but cannot run this scene (%s; and no ordered walk)", s->fast_why);
     RT_HIP(hipSetDevice(s->device));
     const size_t N = (size_t)n;
     float *d_rays = nullptr;
@@ -734,7 +866,9 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
     hipError_t e = hipMalloc(&d_hits, sizeof(rt_hit) * N);
     if (e == hipSuccess) e = hipMemcpy(d_rays, h_rays, 28 * N, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        if (s->trace_path == RT_PATH_FAST)
+        if (s->trace_path == RT_PATH_FAST && s->lanes_ok)
+            hipLaunchKernelGGL(trace_fastlanes_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
+        else if (s->trace_path == RT_PATH_FAST)
             hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
                                d_rays, t_min, t_max, d_hits);
         else if (s->dev.n_entries > RT_UNIFORM_WALK_MAX)
@@ -755,8 +889,8 @@ extern "C" int rt_scene_set_option(rt_scene *s, int option, int value)
     if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: null scene");
     if (value != RT_PATH_AUTO && value != RT_PATH_EXACT && value != RT_PATH_FAST)
         return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: value %d", value);
-    if (value == RT_PATH_FAST && !s->fast_ok)
-        return rt_fail(RT_ERR_UNSUPPORTED, "rt_scene_set_option: the scene does not fit the register-resident path: %s", s->fast_why);
+    if (value == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
+        return rt_fail(RT_ERR_UNSUPPORTED, "rt_scene_set_option: the fast path cannot run this scene (%s; and no ordered walk)", s->fast_why);
     if (option == RT_OPT_RENDER_PATH) s->render_path = value;
     else if (option == RT_OPT_TRACE_PATH) s->trace_path = value;
     else return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: unknown option %d", option);
@@ -767,7 +901,7 @@ extern "C" int rt_scene_get_info(rt_scene *s, int what, int *value)
 {
     if (!s || !value) return rt_fail(RT_ERR_INVALID, "rt_scene_get_info: null argument");
     switch (what) {
-    case RT_INFO_FAST_PATH_AVAILABLE: *value = s->fast_ok ? 1 : 0; return RT_OK;
+    case RT_INFO_FAST_PATH_AVAILABLE: *value = (s->fast_ok || s->lanes_ok) ? 1 : 0; return RT_OK;
     case RT_INFO_LAST_RENDER_PATH: *value = s->last_render_path; return RT_OK;
     case RT_INFO_RECORDS: *value = s->fast_ok ? s->layout.lights_base + s->layout.n_lights : -1; return RT_OK;
     }

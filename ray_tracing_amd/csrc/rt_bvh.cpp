@@ -1,0 +1,234 @@
+// rt_bvh.cpp -- binned-SAH BVH2 over the world-space boxes of a scene's primitives (rt_bvh.h).
+#include "rt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void clear() { lo[0] = lo[1] = lo[2] = INFINITY, hi[0] = hi[1] = hi[2] = -INFINITY; }
+    void add(const float p[3])
+    {
+        for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], p[k]), hi[k] = std::max(hi[k], p[k]);
+    }
+    void add(const Box &b)
+    {
+        for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], b.lo[k]), hi[k] = std::max(hi[k], b.hi[k]);
+    }
+    float area() const
+    {
+        float e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (e[0] < 0) return 0.0f;
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    }
+    bool finite() const
+    {
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return false;
+        return true;
+    }
+};
+
+struct Item {
+    Box b;
+    float c[3];
+    int32_t prim;
+};
+
+// local box of a primitive (src/sphere.h:61-66, 185-196; src/plane.h:31-35 and siblings; src/box.h:25-29)
+bool local_box(const rt_scene_desc *d, const rt_prim &p, Box &b)
+{
+    b.clear();
+    switch (p.kind) {
+    case RT_PRIM_SPHERE: {
+        float r = std::fabs(p.f[3]);
+        for (int k = 0; k < 3; ++k) b.lo[k] = p.f[k] - r, b.hi[k] = p.f[k] + r;
+        return true;
+    }
+    case RT_PRIM_MOVING_SPHERE: {
+        float r = std::fabs(p.f[6]);
+        for (int k = 0; k < 3; ++k)
+            b.lo[k] = std::min(p.f[k], p.f[3 + k]) - r, b.hi[k] = std::max(p.f[k], p.f[3 + k]) + r;
+        return true;
+    }
+    case RT_PRIM_XY_RECT:
+    case RT_PRIM_XZ_RECT:
+    case RT_PRIM_YZ_RECT: {
+        const int ka = p.kind == RT_PRIM_YZ_RECT ? 1 : 0, kb = p.kind == RT_PRIM_XY_RECT ? 1 : 2, kk = 3 - ka - kb;
+        b.lo[ka] = p.f[0], b.hi[ka] = p.f[1], b.lo[kb] = p.f[2], b.hi[kb] = p.f[3];
+        b.lo[kk] = p.f[4] - 0.0001f, b.hi[kk] = p.f[4] + 0.0001f;
+        return true;
+    }
+    case RT_PRIM_GROUP:
+        for (int k = 0; k < p.count; ++k) {
+            Box c;
+            if (!local_box(d, d->prims[p.first + k], c)) return false;
+            b.add(c);
+        }
+        return true;
+    default: return false;
+    }
+}
+
+// box of a primitive in WORLD space: the eight corners go up its instance chain (src/transforms.h:30-52, 69-100)
+bool world_box(const rt_scene_desc *d, const rt_prim &p, Box &out)
+{
+    const rt_prim &shape = p.kind == RT_PRIM_MEDIUM ? d->prims[p.first] : p;
+    Box l;
+    if (!local_box(d, shape, l)) return false;
+    const rt_chain &c = d->chains[shape.chain];
+    out.clear();
+    for (int corner = 0; corner < 8; ++corner) {
+        float q[3] = {corner & 1 ? l.hi[0] : l.lo[0], corner & 2 ? l.hi[1] : l.lo[1], corner & 4 ? l.hi[2] : l.lo[2]};
+        for (int i = c.count - 1; i >= 0; --i) {
+            const rt_xform &x = d->xforms[c.first + i];
+            if (x.kind == RT_XFORM_TRANSLATE) {
+                q[0] += x.a, q[1] += x.b, q[2] += x.c;
+            } else {
+                const float s = x.a, co = x.b, px = q[0], pz = q[2];
+                q[0] = co * px + s * pz;
+                q[2] = -s * px + co * pz;
+            }
+        }
+        out.add(q);
+    }
+    // float rounding of the rotation: keep the box conservative
+    for (int k = 0; k < 3; ++k) {
+        const float pad = 1e-5f * (std::fabs(out.lo[k]) + std::fabs(out.hi[k])) + 1e-6f;
+        out.lo[k] -= pad, out.hi[k] += pad;
+    }
+    return out.finite();
+}
+
+struct Builder {
+    std::vector<Item> items;
+    std::vector<rt_bvh_node> *nodes;
+    int max_depth = 0;
+    bool ok = true;
+
+    static int log2_ceil(size_t n)
+    {
+        int l = 0;
+        while (((size_t)1 << l) < n) ++l;
+        return l;
+    }
+
+    // builds the subtree over items [a, b), b - a >= 2, into a new node; returns its index
+    int32_t build(size_t a, size_t b, int depth)
+    {
+        max_depth = std::max(max_depth, depth);
+        if (depth > RT_BVH_MAX_DEPTH) return ok = false, 0;
+        const int32_t me = (int32_t)nodes->size();
+        nodes->push_back(rt_bvh_node{});
+        const size_t n = b - a;
+        Box cb;
+        cb.clear();
+        for (size_t i = a; i < b; ++i) cb.add(items[i].c);
+        size_t mid = a + n / 2;
+        int axis = 0;
+        for (int k = 1; k < 3; ++k)
+            if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        // the stack bound: once the remaining depth only just fits a balanced tree, split at the median
+        const bool force_median = depth + log2_ceil(n) >= RT_BVH_MAX_DEPTH - 1;
+        bool split_done = false;
+        if (!force_median && n > 2) {
+            constexpr int NB = 16;
+            float best_cost = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int k = 0; k < 3; ++k) {
+                const float ext = cb.hi[k] - cb.lo[k];
+                if (!(ext > 0.0f)) continue;
+                Box bb[NB];
+                size_t cnt[NB] = {0};
+                for (Box &x : bb) x.clear();
+                const float scale = NB / ext;
+                for (size_t i = a; i < b; ++i) {
+                    int bin = std::min(NB - 1, std::max(0, (int)((items[i].c[k] - cb.lo[k]) * scale)));
+                    bb[bin].add(items[i].b);
+                    ++cnt[bin];
+                }
+                float right_area[NB];
+                Box acc;
+                acc.clear();
+                size_t right_cnt[NB];
+                size_t rc = 0;
+                for (int i = NB - 1; i > 0; --i) {
+                    acc.add(bb[i]);
+                    rc += cnt[i];
+                    right_area[i] = acc.area(), right_cnt[i] = rc;
+                }
+                acc.clear();
+                size_t lc = 0;
+                for (int i = 0; i < NB - 1; ++i) {
+                    acc.add(bb[i]);
+                    lc += cnt[i];
+                    if (lc == 0 || right_cnt[i + 1] == 0) continue;
+                    const float cost = acc.area() * (float)lc + right_area[i + 1] * (float)right_cnt[i + 1];
+                    if (cost < best_cost) best_cost = cost, best_axis = k, best_bin = i;
+                }
+            }
+            if (best_axis >= 0) {
+                const float ext = cb.hi[best_axis] - cb.lo[best_axis], scale = 16 / ext, lo = cb.lo[best_axis];
+                const int bax = best_axis, bbin = best_bin;
+                auto it = std::partition(items.begin() + a, items.begin() + b, [=](const Item &x) {
+                    int bin = std::min(15, std::max(0, (int)((x.c[bax] - lo) * scale)));
+                    return bin <= bbin;
+                });
+                mid = (size_t)(it - items.begin());
+                split_done = mid > a && mid < b;
+            }
+        }
+        if (!split_done) {
+            mid = a + n / 2;
+            std::nth_element(items.begin() + a, items.begin() + mid, items.begin() + b,
+                             [axis](const Item &x, const Item &y) { return x.c[axis] < y.c[axis]; });
+        }
+        Box b0, b1;
+        b0.clear(), b1.clear();
+        for (size_t i = a; i < mid; ++i) b0.add(items[i].b);
+        for (size_t i = mid; i < b; ++i) b1.add(items[i].b);
+        const int32_t r0 = mid - a == 1 ? ~items[a].prim : build(a, mid, depth + 1);
+        const int32_t r1 = b - mid == 1 ? ~items[mid].prim : build(mid, b, depth + 1);
+        rt_bvh_node &nd = (*nodes)[me];
+        for (int k = 0; k < 3; ++k) nd.lo0[k] = b0.lo[k], nd.hi0[k] = b0.hi[k], nd.lo1[k] = b1.lo[k], nd.hi1[k] = b1.hi[k];
+        nd.ref0 = r0, nd.ref1 = r1;
+        return me;
+    }
+};
+
+} // namespace
+
+bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, int *depth)
+{
+    nodes.clear();
+    Builder B;
+    B.nodes = &nodes;
+    std::vector<char> seen((size_t)d->n_prims, 0);
+    for (int e = 0; e < d->n_entries; ++e) {
+        if ((d->entries[e].b & 255) != RT_ENTRY_LEAF) continue;
+        const int32_t pi = d->entries[e].a;
+        if (seen[pi]) continue; // a one-primitive bvh_node holds its primitive twice (src/bvh.h:98-101)
+        seen[pi] = 1;
+        Item it;
+        if (!world_box(d, d->prims[pi], it.b)) return false;
+        for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (it.b.lo[k] + it.b.hi[k]);
+        it.prim = pi;
+        B.items.push_back(it);
+    }
+    if (B.items.empty()) return false;
+    nodes.reserve(B.items.size());
+    if (B.items.size() == 1) { // a root with one child
+        rt_bvh_node nd{};
+        for (int k = 0; k < 3; ++k) nd.lo0[k] = B.items[0].b.lo[k], nd.hi0[k] = B.items[0].b.hi[k], nd.lo1[k] = 1.0f, nd.hi1[k] = -1.0f;
+        nd.ref0 = ~B.items[0].prim, nd.ref1 = RT_BVH_NONE;
+        nodes.push_back(nd);
+        *depth = 1;
+        return true;
+    }
+    B.build(0, B.items.size(), 1);
+    *depth = B.max_depth;
+    return B.ok;
+}

@@ -24,6 +24,7 @@
 
 #include "../../include/rt_amd.h"
 #include "../../include/rt_rng.h"
+#include "rt_bvh.h"
 #include "rt_order.h"
 
 #define RT_PI 3.14159f           // src/main.cpp:54-56
@@ -99,6 +100,7 @@ struct DevScene {
     const rt_texture *textures;
     const uint8_t *texels;
     const int32_t *lights;
+    const ::rt_bvh_node *bvh; // rt_bvh.h: the fast per-lane path's own tree, or null
     const int2 *ord; // rt_order.h: per inner entry {right child, flags}; only read when ordered != 0
     int32_t n_entries, n_lights;
     int32_t ordered; // the entries are a binary tree no deeper than RT_ORD_MAX_DEPTH: world_hit_ordered may be used

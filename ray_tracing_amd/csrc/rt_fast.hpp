@@ -210,6 +210,7 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray 
 // what shading needs about the hit, built after the scan from the winning record
 struct Surface {
     V3 p, n;
+    float u, v; // only where a texture reads them
     uint32_t mat_kind;
     int32_t texture;
     float p0;
@@ -222,6 +223,7 @@ RTF_DEV void build_surface(const Regs &R, const Layout &Y, const Ray &wr, float 
     const float f0 = sh_f(R.d[0], src), f1 = sh_f(R.d[1], src), f2 = sh_f(R.d[2], src);
     const float f4 = sh_f(R.d[4], src), f5 = sh_f(R.d[5], src), f6 = sh_f(R.d[6], src);
     s.p = fma3(t, wr.d, wr.o);
+    s.u = s.v = 0.0f; // the record table holds no texture that reads (u,v)
     if ((kw & 15u) == RT_REC_SPHERE) {
         const float k = (kw & RT_KW_FLIP) ? -f4 : f4; // (p - c) / r, src/sphere.h:41, then flip_normals
         s.n = v3((s.p.x - f0) * k, (s.p.y - f1) * k, (s.p.z - f2) * k);
@@ -351,7 +353,7 @@ RTF_DEV bool shade(const DevScene &S, const uint32_t *__restrict__ recs, const L
     L = v3(0, 0, 0);
     if (!hit_any) return false;
     V3 albedo = h.color;
-    if (TEX && h.texture >= 0) albedo = rt::tex_value(S, h.texture, 0.0f, 0.0f, h.p);
+    if (TEX && h.texture >= 0) albedo = rt::tex_value(S, h.texture, h.u, h.v, h.p);
     if (h.mat_kind == RT_MAT_DIFFUSE_LIGHT) {
         L = v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
         return false;

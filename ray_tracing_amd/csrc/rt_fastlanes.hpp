@@ -1,0 +1,229 @@
+// rt_fastlanes.hpp -- the fast render path for scenes that do NOT fit the record table (rt_records.h):
+// hundreds to millions of primitives, media, moving spheres, textures.
+//
+// Same algorithm and same random-draw order per primitive as the exact path, different machine mapping and
+// arithmetic, like rt_fast.hpp for small scenes:
+//   * every lane walks a tree on its own -- the library's tree over the same primitives (rt_bvh.h: world-space
+//     boxes, surface-area splits, both children's boxes in one 64-byte node), nearer child first, a box entered
+//     only if the ray reaches it before the best hit so far, pending children in a per-lane stack in LDS.
+//     The closest hit over a set of primitives does not depend on the tree or on the order of the visits
+//     (rt_device.hpp, world_hit_ordered, explains why); which of two hits at EQUAL distance wins may differ
+//     here, and a constant_medium that lies behind the best hit is not visited, so it draws no random number:
+//     its hit would have lost anyway, and the draws are independent, so the image has the same distribution
+//     (tests compare the two paths hit by hit and statistically).
+//   * during the walk a lane keeps (t, primitive index); point, normal, (u,v) and material are built once per
+//     ray from the winner.
+//   * hardware-rate reciprocal / sqrt / log, FMA contraction, 1/d hoisted.
+#ifndef RT_FASTLANES_HPP_
+#define RT_FASTLANES_HPP_
+
+#include "rt_bvh.h"
+#include "rt_fast.hpp"
+
+namespace rtf {
+#pragma clang fp contract(fast)
+
+RTF_DEV V3 rcp3(V3 d) { return v3(rcp(d.x), rcp(d.y), rcp(d.z)); }
+
+// sphere / moving_sphere / rect in its own space: t only.  src/sphere.h:21-59, 147-183; src/plane.h:9-29, 47-67, 109-129
+RTF_DEV bool plain_t(const rt_prim &pr, const Ray &lr, V3 inv, float dd, float inv_dd, float t_min, float t_max, float &t)
+{
+    const int kind = pr.kind;
+    if (kind <= RT_PRIM_MOVING_SPHERE) {
+        V3 c;
+        float radius;
+        if (kind == RT_PRIM_SPHERE) {
+            c = v3(pr.f[0], pr.f[1], pr.f[2]);
+            radius = pr.f[3];
+        } else { // center(time), src/sphere.h:142-145
+            const float k = (lr.time - pr.f[7]) * rcp(pr.f[8] - pr.f[7]);
+            c = v3(fmaf(k, pr.f[3] - pr.f[0], pr.f[0]), fmaf(k, pr.f[4] - pr.f[1], pr.f[1]), fmaf(k, pr.f[5] - pr.f[2], pr.f[2]));
+            radius = pr.f[6];
+        }
+        const V3 oc = v3(lr.o.x - c.x, lr.o.y - c.y, lr.o.z - c.z);
+        const float b = fdot(oc, lr.d);
+        const float cc = fmaf(-radius, radius, fdot(oc, oc));
+        const float disc = fmaf(b, b, -(dd * cc));
+        const float sq = fsqrt(disc);
+        const float t1 = (-b - sq) * inv_dd, t2 = (-b + sq) * inv_dd;
+        const bool in1 = (t1 < t_max) & (t1 > t_min), in2 = (t2 < t_max) & (t2 > t_min);
+        t = in1 ? t1 : t2;
+        return (disc > 0.0f) & (in1 | in2);
+    }
+    const bool xy = kind == RT_PRIM_XY_RECT, xz = kind == RT_PRIM_XZ_RECT;
+    const float ok = xy ? lr.o.z : xz ? lr.o.y : lr.o.x, ik = xy ? inv.z : xz ? inv.y : inv.x;
+    const float oa = (xy | xz) ? lr.o.x : lr.o.y, da = (xy | xz) ? lr.d.x : lr.d.y;
+    const float ob = xy ? lr.o.y : lr.o.z, db = xy ? lr.d.y : lr.d.z;
+    t = (pr.f[4] - ok) * ik;
+    const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
+    return (t >= t_min) & (t <= t_max) & (a >= pr.f[0]) & (a <= pr.f[1]) & (b >= pr.f[2]) & (b <= pr.f[3]);
+}
+
+// a plain primitive or a list (box): hitable_list::hit, src/hitable_list.h:18-34
+RTF_DEV bool simple_t(const DevScene &S, int idx, const rt_prim &pr, const Ray &lr, V3 inv, float dd, float inv_dd, float t_min,
+                      float t_max, float &t, int &which)
+{
+    if (pr.kind != RT_PRIM_GROUP) {
+        which = idx;
+        return plain_t(pr, lr, inv, dd, inv_dd, t_min, t_max, t);
+    }
+    bool h = false;
+    float closest = t_max;
+    for (int k = 0; k < pr.count; ++k) {
+        float ct;
+        if (plain_t(S.prims[pr.first + k], lr, inv, dd, inv_dd, t_min, closest, ct)) {
+            h = true;
+            closest = ct;
+            t = ct, which = pr.first + k;
+        }
+    }
+    return h;
+}
+
+// world->hit() over the library's own tree (rt_bvh.h): closest t and the primitive that gave it (a MEDIUM
+// primitive for a hit inside a constant_medium).  Boxes are in world space; a leaf under an instance chain
+// takes the ray down its chain (src/transforms.h:17, 107-110) when the lane gets there.
+RTF_DEV bool hit_bvh(const DevScene &S, const Ray &wr, float t_min, float t_max, bool alive, Rng &rng, float &best_t, int &best_prim,
+                     int *stack)
+{
+    best_t = t_max;
+    best_prim = -1;
+    int sp = 0;
+    int cur = alive ? 0 : RT_BVH_NONE;
+    const V3 winv = rcp3(wr.d);
+    // t = lo * inv - o * inv, one FMA per plane.  Where 1/d overflows the two terms can cancel to NaN; min/max drop a
+    // NaN, which only ever makes a box easier to enter.
+    const V3 noi = v3(-wr.o.x * winv.x, -wr.o.y * winv.y, -wr.o.z * winv.z);
+    int cur_chain = 0;
+    Ray lr = wr;
+    V3 inv = winv;
+    const float dd = fdot(wr.d, wr.d), inv_dd = rcp(dd); // chains are rigid: d.d is the same in every space
+
+    while (__any(cur != RT_BVH_NONE)) {
+        while (cur >= 0) { // inner node: both children's boxes, far bound = best hit so far
+            const uint4 *q = reinterpret_cast<const uint4 *>(S.bvh + cur);
+            const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+            const float tn0 = fmaxf(fmax3(fminf(fmaf(__uint_as_float(a0.x), winv.x, noi.x), fmaf(__uint_as_float(a1.x), winv.x, noi.x)),
+                                          fminf(fmaf(__uint_as_float(a0.y), winv.y, noi.y), fmaf(__uint_as_float(a1.y), winv.y, noi.y)),
+                                          fminf(fmaf(__uint_as_float(a0.z), winv.z, noi.z), fmaf(__uint_as_float(a1.z), winv.z, noi.z))),
+                                    t_min);
+            const float tf0 = fminf(fmin3(fmaxf(fmaf(__uint_as_float(a0.x), winv.x, noi.x), fmaf(__uint_as_float(a1.x), winv.x, noi.x)),
+                                          fmaxf(fmaf(__uint_as_float(a0.y), winv.y, noi.y), fmaf(__uint_as_float(a1.y), winv.y, noi.y)),
+                                          fmaxf(fmaf(__uint_as_float(a0.z), winv.z, noi.z), fmaf(__uint_as_float(a1.z), winv.z, noi.z))),
+                                    best_t);
+            const float tn1 = fmaxf(fmax3(fminf(fmaf(__uint_as_float(a2.x), winv.x, noi.x), fmaf(__uint_as_float(a3.x), winv.x, noi.x)),
+                                          fminf(fmaf(__uint_as_float(a2.y), winv.y, noi.y), fmaf(__uint_as_float(a3.y), winv.y, noi.y)),
+                                          fminf(fmaf(__uint_as_float(a2.z), winv.z, noi.z), fmaf(__uint_as_float(a3.z), winv.z, noi.z))),
+                                    t_min);
+            const float tf1 = fminf(fmin3(fmaxf(fmaf(__uint_as_float(a2.x), winv.x, noi.x), fmaf(__uint_as_float(a3.x), winv.x, noi.x)),
+                                          fmaxf(fmaf(__uint_as_float(a2.y), winv.y, noi.y), fmaf(__uint_as_float(a3.y), winv.y, noi.y)),
+                                          fmaxf(fmaf(__uint_as_float(a2.z), winv.z, noi.z), fmaf(__uint_as_float(a3.z), winv.z, noi.z))),
+                                    best_t);
+            const int ref0 = (int)a0.w, ref1 = (int)a1.w;
+            const bool h0 = tf0 >= tn0, h1 = (tf1 >= tn1) & (ref1 != RT_BVH_NONE);
+            const bool first0 = tn0 <= tn1;
+            const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
+            const bool hn = first0 ? h0 : h1, hf = first0 ? h1 : h0;
+            if (hn & hf) {
+                stack[sp++ * 64] = far;
+                cur = near;
+            } else if (hn | hf) {
+                cur = hn ? near : far;
+            } else {
+                cur = sp > 0 ? stack[--sp * 64] : RT_BVH_NONE;
+            }
+        }
+        if (cur != RT_BVH_NONE) { // a leaf
+            const int leaf = ~cur;
+            const rt_prim &pr = S.prims[leaf];
+            const int chain = pr.kind == RT_PRIM_MEDIUM ? S.prims[pr.first].chain : pr.chain;
+            if (chain != cur_chain) {
+                lr = rt::chain_down(S, chain, wr);
+                inv = rcp3(lr.d);
+                cur_chain = chain;
+            }
+            float t = 0.0f;
+            int which = leaf;
+            bool h;
+            if (pr.kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment)
+                const rt_prim &bp = S.prims[pr.first];
+                float t1 = 0.0f, t2 = 0.0f;
+                int dummy;
+                h = false;
+                if (simple_t(S, pr.first, bp, lr, inv, dd, inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
+                    simple_t(S, pr.first, bp, lr, inv, dd, inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy)) {
+                    t1 = fminf(fmaxf(t1, t_min), best_t);
+                    if (t1 < t2) {
+                        t1 = fmaxf(t1, 0.0f);
+                        const float hit_distance = -rcp(pr.f[0]) * __logf(rng.next());
+                        t = fmaf(hit_distance, rsq(dd), t1);
+                        h = true;
+                    }
+                }
+            } else {
+                h = simple_t(S, leaf, pr, lr, inv, dd, inv_dd, t_min, best_t, t, which);
+            }
+            const bool take = h & (t <= best_t);
+            best_t = take ? t : best_t;
+            best_prim = take ? which : best_prim;
+            cur = sp > 0 ? stack[--sp * 64] : RT_BVH_NONE;
+        }
+    }
+    return best_prim >= 0;
+}
+
+// point, normal, (u,v), material of the winner; every lane for itself
+RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int prim, Surface &s)
+{
+    const rt_prim &pr = S.prims[prim < 0 ? 0 : prim];
+    s.p = fma3(t, wr.d, wr.o);
+    s.u = s.v = 0.0f;
+    const int kind = pr.kind;
+    V3 n = v3(1, 0, 0); // constant_medium: src/volume.h:47
+    if (kind != RT_PRIM_MEDIUM) {
+        const Ray lr = pr.chain == 0 ? wr : rt::chain_down(S, pr.chain, wr);
+        const V3 pl = fma3(t, lr.d, lr.o);
+        if (kind <= RT_PRIM_MOVING_SPHERE) {
+            V3 c;
+            float radius;
+            if (kind == RT_PRIM_SPHERE) {
+                c = v3(pr.f[0], pr.f[1], pr.f[2]);
+                radius = pr.f[3];
+            } else {
+                const float k = (lr.time - pr.f[7]) * rcp(pr.f[8] - pr.f[7]);
+                c = v3(fmaf(k, pr.f[3] - pr.f[0], pr.f[0]), fmaf(k, pr.f[4] - pr.f[1], pr.f[1]), fmaf(k, pr.f[5] - pr.f[2], pr.f[2]));
+                radius = pr.f[6];
+            }
+            const float ir = rcp(radius);
+            n = v3((pl.x - c.x) * ir, (pl.y - c.y) * ir, (pl.z - c.z) * ir);
+            if (pr.flags & RT_PRIM_NEEDS_UV) rt::sphere_uv(n, s.u, s.v); // before the flip, as sphere::hit does
+        } else {
+            const bool xy = kind == RT_PRIM_XY_RECT, xz = kind == RT_PRIM_XZ_RECT;
+            n = v3((xy | xz) ? 0.0f : 1.0f, xz ? 1.0f : 0.0f, xy ? 1.0f : 0.0f);
+            if (pr.flags & RT_PRIM_NEEDS_UV) {
+                const float a = (xy | xz) ? pl.x : pl.y, b = xy ? pl.y : pl.z;
+                s.u = (a - pr.f[0]) * rcp(pr.f[1] - pr.f[0]);
+                s.v = (b - pr.f[2]) * rcp(pr.f[3] - pr.f[2]);
+            }
+        }
+        if (pr.flags & RT_PRIM_FLIP) n = v3(-n.x, -n.y, -n.z);
+        if (pr.chain != 0) {
+            V3 dummy = pl;
+            rt::chain_up(S, pr.chain, dummy, n);
+        }
+    }
+    s.n = n;
+    const rt_material m = S.materials[pr.material < 0 ? 0 : pr.material];
+    s.mat_kind = (uint32_t)m.kind;
+    s.p0 = m.p0;
+    s.texture = -1;
+    s.color = v3(1, 1, 1);
+    if (m.texture >= 0) {
+        const rt_texture &tx = S.textures[m.texture];
+        if (tx.kind == RT_TEX_CONSTANT) s.color = v3(tx.color[0], tx.color[1], tx.color[2]);
+        else s.texture = m.texture;
+    }
+}
+
+} // namespace rtf
+#endif // RT_FASTLANES_HPP_

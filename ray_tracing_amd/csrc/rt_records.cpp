@@ -44,6 +44,28 @@ void chain_up_normal(const rt_scene_desc *d, int chain, float n[3])
     }
 }
 
+// the light records (important_hitables), from record `at` on; returns the index after them
+int emit_lights(const rt_scene_desc *d, rt_record_table *out, int at)
+{
+    for (int l = 0; l < d->n_lights; ++l, ++at) {
+        uint32_t *r = out->rec[at];
+        int pi = d->lights[l];
+        if (pi < 0) {
+            r[7] = RT_REC_LIGHT_NONE;
+            continue;
+        }
+        const rt_prim &p = d->prims[pi];
+        for (int k = 0; k < 5; ++k) r[k] = fbits(p.f[k]);
+        if (p.kind == RT_PRIM_XZ_RECT) {
+            r[5] = fbits((p.f[1] - p.f[0]) * (p.f[3] - p.f[2])); // area, src/plane.h:82
+            r[7] = RT_REC_LIGHT_RECT;
+        } else {
+            r[7] = RT_REC_LIGHT_SPHERE;
+        }
+    }
+    return at;
+}
+
 } // namespace
 
 extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, const char **why)
@@ -148,22 +170,7 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
     }
     out->lights_base = at;
     out->n_lights = d->n_lights;
-    for (int l = 0; l < d->n_lights; ++l, ++at) {
-        uint32_t *r = out->rec[at];
-        int pi = d->lights[l];
-        if (pi < 0) {
-            r[7] = RT_REC_LIGHT_NONE;
-            continue;
-        }
-        const rt_prim &p = d->prims[pi];
-        for (int k = 0; k < 5; ++k) r[k] = fbits(p.f[k]);
-        if (p.kind == RT_PRIM_XZ_RECT) {
-            r[5] = fbits((p.f[1] - p.f[0]) * (p.f[3] - p.f[2])); // area, src/plane.h:82
-            r[7] = RT_REC_LIGHT_RECT;
-        } else {
-            r[7] = RT_REC_LIGHT_SPHERE;
-        }
-    }
+    at = emit_lights(d, out, at);
     out->n_records = at;
     out->n_stream = n_stream;
     out->flat = keep_inner ? 0 : 1;
@@ -218,5 +225,22 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             emit_prim(s, en.a, p, p.chain, RT_KW_FIRST | RT_KW_LAST);
         }
     }
+    return 1;
+}
+
+// A table that holds only the light records (for scenes that do not fit: the per-lane fast path samples the
+// important list from it, the scene itself stays in the generic tables).
+extern "C" int rt_records_build_lights(const rt_scene_desc *d, rt_record_table *out)
+{
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < RT_REC_MAX; ++i) out->user_id[i] = out->prim[i] = -1;
+    if (d->n_lights > RT_REC_MAX) return 0;
+    // lights must be usable from WORLD space: a light under an instance chain has no pdf_value/random of its own
+    // in the reference either (translate / rotate_y do not forward them, src/hitable.h:19-20); the flattener
+    // writes -1 for those.
+    out->lights_base = 0;
+    out->n_lights = d->n_lights;
+    out->n_records = emit_lights(d, out, 0);
+    out->flat = 1;
     return 1;
 }

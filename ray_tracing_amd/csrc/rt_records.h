@@ -69,6 +69,8 @@ extern "C" {
  * spheres, no texture that needs (u,v)), 0 if it does not (the caller then uses
  * the generic memory-resident path).  `why` receives a short reason. */
 int rt_records_build(const rt_scene_desc *d, rt_record_table *out, const char **why);
+/* Lights only (n_stream = 0): for scenes that do not fit.  Returns 0 if there are more than 64 lights. */
+int rt_records_build_lights(const rt_scene_desc *d, rt_record_table *out);
 #ifdef __cplusplus
 }
 #endif

@@ -270,9 +270,8 @@ def test_ext_scene_trace_equals_oracle_and_reference(scene):
     tab = np.load(os.path.join(O.GOLD, f"{scene}.npz"))["hits_64x48"].reshape(-1, 21)
     hs = HostScene(scene, 64 / 48)
     sc = Scene(hs, 0)
-    assert sc.info(_capi.RT_INFO_FAST_PATH_AVAILABLE) == 0
-    with pytest.raises(api.RtError):
-        sc.set_path(render=_capi.RT_PATH_FAST)
+    # too large (or too rich) for the record table; the fast path for them is the per-lane one (rt_fastlanes.hpp)
+    assert sc.info(_capi.RT_INFO_RECORDS) == -1 and sc.info(_capi.RT_INFO_FAST_PATH_AVAILABLE) == 1
     rays = tab[:, 2:9].copy()
     g, c = api.trace_rays(sc, rays, seed=5), O.trace_rays(hs, rays, seed=5)
     sc.close()
@@ -308,10 +307,75 @@ def test_ext_scene_render_matches_oracle_on_the_same_stream(scene, nx, ny, ns):
     so a few more paths diverge: >= 93 % of pixels within 1e-3, image mean within 3 %."""
     hs = HostScene(scene, nx / ny)
     sc = Scene(hs, 0)
+    sc.set_path(render=_capi.RT_PATH_EXACT)
     g = gpu_render(sc, nx, ny, 0, ns, seed=9)
+    assert sc.info(_capi.RT_INFO_LAST_RENDER_PATH) == _capi.RT_PATH_EXACT
     sc.close()
     c, _, _ = O.render(hs, nx, ny, 0, ns, 1, 50, O.ORC_RNG_COUNTER, 9, 8)
     close = np.isclose(g[..., 1:], c[..., 1:], rtol=1e-3, atol=1e-4).all(axis=-1)
     assert close.mean() >= 0.93, f"only {close.mean():.4f} of pixels agree"
     gm, cmn = g[..., 1:].mean(axis=(0, 1)), c[..., 1:].mean(axis=(0, 1))
     assert np.allclose(gm, cmn, rtol=3e-2, atol=1e-4), (gm, cmn)
+
+
+@pytest.mark.parametrize("scene", EXT)
+def test_ext_scene_fast_trace_close_to_exact(scene):
+    """The per-lane fast path (ordered, culled walk, hardware-rate arithmetic) finds the same closest hits as the exact
+    path up to rounding.  Media draw random numbers, so their hits are compared only through which rays they involve."""
+    tab = np.load(os.path.join(O.GOLD, f"{scene}.npz"))["hits_64x48"].reshape(-1, 21)
+    hs = HostScene(scene, 64 / 48)
+    sc = Scene(hs, 0)
+    rng = np.random.default_rng(17)
+    n = 20000
+    lo, hi = (0.0, 555.0) if scene != "random_spheres" else (-8.0, 8.0)
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    if scene == "random_spheres":
+        o[:, 1] = np.abs(o[:, 1]) * 0.5 + 0.05
+    if scene == "next_week_final":
+        # above the ground boxes (height <= 101): neighbouring boxes share walls, and a ray that starts INSIDE one meets two
+        # coincident faces at the same t, where the two walks are free to pick different winners (ties: rt_fastlanes.hpp)
+        o[:, 1] = 110.0 + o[:, 1] * 0.8
+    dvec = rng.normal(size=(n, 3)).astype(np.float32)
+    rays = np.concatenate([tab[:, 2:9].astype(np.float32), np.concatenate([o, dvec, rng.uniform(size=(n, 1)).astype(np.float32)], axis=1)])
+    exact = api.trace_rays(sc, rays, seed=5)
+    sc.set_path(trace=_capi.RT_PATH_FAST)
+    fast = api.trace_rays(sc, rays, seed=5)
+    sc.close()
+    d = hs.desc.contents
+    iso = np.array([d.materials[i].kind == _capi.RT_MAT_ISOTROPIC for i in range(d.n_materials)])
+    em = (exact["material"] >= 0) & iso[np.maximum(exact["material"], 0)]
+    fm = (fast["material"] >= 0) & iso[np.maximum(fast["material"], 0)]
+    solid = ~em & ~fm
+    assert solid.mean() > 0.3
+    same = exact["prim_id"][solid] == fast["prim_id"][solid]
+    assert same.mean() >= 0.999, f"{(~same).sum()} of {solid.sum()} ids differ"
+    m = np.flatnonzero(solid)[same & (exact["prim_id"][solid] >= 0)]
+    assert np.allclose(fast["t"][m], exact["t"][m], rtol=1e-3, atol=1e-3)
+    assert np.array_equal(fast["material"][m], exact["material"][m])
+    # float32 loses digits on the radius-1000 ground sphere (b*b - a*c cancels), differently on the two paths
+    dn = np.abs(fast["normal"][m] - exact["normal"][m]).max(axis=1)
+    assert (dn <= 2e-3).mean() >= 0.995 and dn.max() <= 0.05, (dn.max(), (dn > 2e-3).sum())
+    dp = np.abs(fast["p"][m] - exact["p"][m]).max(axis=1)
+    assert (dp <= 0.05).mean() >= 0.995 and dp.max() <= 5.0, (dp.max(), (dp > 0.05).sum())
+    uv = m[exact["u"][m] != 0]
+    assert np.allclose(fast["u"][uv], exact["u"][uv], atol=1e-3) and np.allclose(fast["v"][uv], exact["v"][uv], atol=1e-3)
+    # the fraction of rays that end inside a medium is a property of the scene, not of the path
+    assert abs(em.mean() - fm.mean()) < 0.02
+
+
+@pytest.mark.parametrize("scene,nx,ny,spp", [("cornell_box_volumes", 64, 64, 64), ("random_spheres", 96, 64, 64), ("next_week_final", 64, 64, 32)])
+def test_ext_scene_fast_render_statistics(scene, nx, ny, spp):
+    """The per-lane fast path (what AUTO picks for trees above 64 entries).  Its image is an independent unbiased estimate of the same
+    integral as the exact path's: per-channel image means agree within 3 standard errors (estimated from 8 batches per path)."""
+    sc = Scene(HostScene(scene, nx / ny), 0)
+    means = {}
+    for name, path in (("fast", _capi.RT_PATH_FAST), ("exact", _capi.RT_PATH_EXACT)):
+        sc.set_path(render=path)
+        b = np.array([gpu_render(sc, nx, ny, k * spp, (k + 1) * spp, seed=31 if name == "fast" else 32)[..., 1:].mean(axis=(0, 1)) / spp
+                      for k in range(8)])
+        assert sc.info(_capi.RT_INFO_LAST_RENDER_PATH) == (_capi.RT_PATH_FAST if name == "fast" else _capi.RT_PATH_EXACT)
+        means[name] = (b.mean(axis=0), b.std(axis=0, ddof=1) / np.sqrt(len(b)))
+    sc.close()
+    diff = np.abs(means["fast"][0] - means["exact"][0])
+    se = np.sqrt(means["fast"][1] ** 2 + means["exact"][1] ** 2)
+    assert np.all(diff <= 3.0 * se + 1e-5), (scene, diff, se, means)
