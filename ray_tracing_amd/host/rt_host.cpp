@@ -54,6 +54,8 @@ const named_scene k_scenes[] = {
     {"cornell_box_volumes", cornell_box_volumes},
     {"random_spheres", random_spheres},
     {"next_week_final", next_week_final},
+    {"sphere_field_4k", sphere_field_4k},
+    {"sphere_field_1m", sphere_field_1m},
 };
 uint32_t g_state_after_build = 0;
 } // namespace

@@ -16,6 +16,7 @@
 #ifndef RT_SCENES_EXT_H_
 #define RT_SCENES_EXT_H_
 
+#include <cmath>
 #include <cstring>
 
 // provided by whoever includes this file: RGB pixels of data/earth.jpg (1024x512), or nullptr
@@ -153,12 +154,63 @@ inline void next_week_final(hitable **scene, hitable **important_hitables, camer
                       800.0f, 0.0f, 1.0f);
 }
 
+// BASELINE.json config 5: "procedural 1M-sphere scene (deep BVH, incoherent secondary rays)".  The reference holds no
+// such scene; this one is written in its style so that the reference's own code can render it too (the harness does, at
+// 4096 spheres, for the golden vectors).  DECISION, all of it: n spheres of radius 0.25 with centres uniform in a cube of
+// half-side 0.5*cbrt(n) (6.5 % of the volume is sphere at any n), 70 % lambertian / 20 % metal / 10 % glass, one light
+// panel above the cube (the important list), camera outside a corner.  One bvh_node over everything, as main() builds it.
+inline void sphere_field(int n, hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    const float half = 0.5f * cbrtf((float)n);
+    hitable **list = new hitable *[n + 1];
+    for (int i = 0; i < n; ++i) {
+        float x = half * (2.0f * RAN01() - 1.0f);
+        float y = half * (2.0f * RAN01() - 1.0f);
+        float z = half * (2.0f * RAN01() - 1.0f);
+        float choose_mat = RAN01();
+        material *m;
+        if (choose_mat < 0.7f) {
+            float r0 = RAN01() * RAN01();
+            float g0 = RAN01() * RAN01();
+            float b0 = RAN01() * RAN01();
+            m = new lambertian(new constant_texture(vec3(0.1f + 0.9f * r0, 0.1f + 0.9f * g0, 0.1f + 0.9f * b0)));
+        } else if (choose_mat < 0.9f) {
+            float r0 = 0.5f * (1.0f + RAN01());
+            float g0 = 0.5f * (1.0f + RAN01());
+            float b0 = 0.5f * (1.0f + RAN01());
+            float fz = 0.3f * RAN01();
+            m = new metal(new constant_texture(vec3(r0, g0, b0)), fz);
+        } else {
+            m = new dielectric(1.5f);
+        }
+        list[i] = new sphere(vec3(x, y, z), 0.25f, m);
+    }
+    hitable *panel = new xz_rect(-half, half, -half, half, 1.5f * half, new diffuse_light(new constant_texture(vec3(5, 5, 5))));
+    list[n] = panel;
+    hitable **imp = new hitable *[1];
+    imp[0] = panel;
+    *important_hitables = new hitable_list(imp, 1);
+    *scene = new hitable_list(list, n + 1);
+    *cam = new camera(vec3(2.6f * half, 1.2f * half, 2.6f * half), vec3(0.0f, 0.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f), 35.0f, aspect, 0.0f,
+                      10.0f, 0.0f, 1.0f);
+}
+inline void sphere_field_4k(hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    sphere_field(4096, scene, important_hitables, cam, aspect);
+}
+inline void sphere_field_1m(hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    sphere_field(1000000, scene, important_hitables, cam, aspect);
+}
+
 typedef void (*rt_ext_scene_fn)(hitable **, hitable **, camera **, float);
 inline rt_ext_scene_fn rt_extra_scene(const char *name)
 {
     if (!strcmp(name, "cornell_box_volumes")) return cornell_box_volumes;
     if (!strcmp(name, "random_spheres")) return random_spheres;
     if (!strcmp(name, "next_week_final")) return next_week_final;
+    if (!strcmp(name, "sphere_field_4k")) return sphere_field_4k;
+    if (!strcmp(name, "sphere_field_1m")) return sphere_field_1m;
     return nullptr;
 }
 

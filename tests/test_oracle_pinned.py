@@ -211,7 +211,7 @@ def test_counter_mode_is_thread_count_invariant(cornell_host):
 # The same scene source is compiled against the reference's headers inside oracle/_ref/ref_harness, which wrote
 # the fixtures with the reference's own hit()/color(); they exercise moving spheres, media, perlin / image
 # textures, metal fuzz, a lens, nested BVHs under translate(rotate_y()).
-EXT = ["cornell_box_volumes", "random_spheres", "next_week_final"]
+EXT = ["cornell_box_volumes", "random_spheres", "next_week_final", "sphere_field_4k"]
 
 
 @pytest.mark.parametrize("scene", EXT)
@@ -253,4 +253,4 @@ def test_ext_scene_primary_hits(scene):
 def test_unsupported_compositions_are_refused():
     lib = _capi.load()
     h = C.c_void_p()
-    assert sorted(lib.rt_host_scene_names().decode().split(",")) == sorted(["cornell_box"] + EXT)
+    assert sorted(lib.rt_host_scene_names().decode().split(",")) == sorted(["cornell_box", "sphere_field_1m"] + EXT)
