@@ -11,7 +11,7 @@ for f in sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), r
     out.append("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
     for r in csv.DictReader(open(f)):
         out.append(f"{r['Name'][:70]:70s} calls {r['Calls']:>4s} avg_ns {float(r['AverageNs']):>14.0f} total_ns {r['TotalDurationNs']:>14s} pct {r['Percentage']}")
-for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
+for p in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5", "pmc6"):
     for f in sorted(glob.glob(os.path.join(d, p, "**", "*counter_collection.csv"), recursive=True)):
         agg = {}
         for r in csv.DictReader(open(f)):
