@@ -364,11 +364,23 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 // The same loop for scenes that do not fit the record table: every lane walks the tree on its own
 // (rt_fastlanes.hpp).  `recs` holds only the light records.
 // ---------------------------------------------------------------------------
+// Lanes do not wait for each other at the end of a bounce: a lane whose walk is over idles until RT_SHADE_BATCH lanes
+// are in that state (or nobody walks any more); then those lanes are shaded, dead ones are refilled from the pool, and
+// all of them start their next walk while the others are still in the middle of theirs.  Likewise lanes standing on a
+// leaf wait until RT_LEAF_BATCH of them do (or nobody is opening nodes).  This keeps the lanes of a wave busy although
+// every ray takes its own number of steps through the tree.
+#ifndef RT_SHADE_BATCH
+#define RT_SHADE_BATCH 40
+#endif
+#ifndef RT_LEAF_BATCH
+#define RT_LEAF_BATCH 16
+#endif
 template <bool TEX>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                                                                                  rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
 {
     __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
+    __shared__ int bvh_stacks[WAVES_PER_BLOCK][RT_BVH_MAX_DEPTH * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -383,7 +395,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fastlanes_kernel(
 
     float *acc = tile_acc[wave];
     acc[lane] = 0.0f, acc[64 + lane] = 0.0f, acc[128 + lane] = 0.0f;
-    __shared__ int bvh_stacks[WAVES_PER_BLOCK][RT_BVH_MAX_DEPTH * 64];
     int *stack = &bvh_stacks[wave][lane];
 
     int next = 0;
@@ -392,52 +403,66 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fastlanes_kernel(
     V3 T = v3(1, 1, 1);
     Rng rng{0u};
     int depth = 0, pix = lane;
+    rtf::Walk w;
+    rtf::walk_start(w, r, RT_FLT_MAX, false);
 
     for (;;) {
-        const unsigned long long dead = __ballot(!alive);
-        if (dead != 0ull && next < total) {
-            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-            const int item = next + rank;
-            if (!alive && item < total) {
-                pix = item & 63;
-                const int q = item >> 6;
-                const int qs = A.sub_samples == 1 ? q : q / A.sub_samples;
-                const int sample = A.sample_begin + s0 + qs;
-                const int sub = q - qs * A.sub_samples;
-                const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
-                if (col < A.nx && row < A.ny) {
-                    rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
-                    const int j = A.ny - 1 - row;
-                    const float u = (float(col) + rng.next()) * inv_nx;
-                    const float v = (float(j) + rng.next()) * inv_ny;
-                    const V3 disk = S.cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
-                    const float time01 = rng.next();
-                    r = rtf::camera_ray(S.cam, u, v, disk, time01);
-                    T = v3(1, 1, 1);
-                    depth = 0;
-                    alive = true;
+        // ---- lanes whose walk is over: shade, refill, start the next walk ----------------------
+        const bool waiting = alive & (w.cur == RT_BVH_NONE);
+        const int n_waiting = __popcll(__ballot(waiting));
+        const bool walking_any = __any(w.cur != RT_BVH_NONE);
+        if (n_waiting >= RT_SHADE_BATCH || !walking_any) {
+            if (waiting) {
+                const bool hit_any = w.best_prim >= 0;
+                rtf::Surface sf;
+                if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
+                V3 L;
+                if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
+                    alive = false;
+                    if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
+                    if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
+                    if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[128 + pix], L.z);
                 }
             }
-            next += __popcll(dead);
-        }
-        if (!__any(alive)) {
-            if (next >= total) break;
-            continue;
-        }
-
-        float t;
-        int prim;
-        const bool hit_any = rtf::hit_bvh(S, r, 0.001f, RT_FLT_MAX, alive, rng, t, prim, stack);
-        if (alive) {
-            rtf::Surface sf;
-            if (hit_any) rtf::build_surface_lanes(S, r, t, prim, sf);
-            V3 L;
-            if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
-                alive = false;
-                if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
-                if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
-                if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[128 + pix], L.z);
+            bool fresh = waiting & alive; // scattered: the new ray is in r
+            const unsigned long long dead = __ballot(!alive);
+            if (dead != 0ull && next < total) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+                const int item = next + rank;
+                if (!alive && item < total) {
+                    pix = item & 63;
+                    const int q = item >> 6;
+                    const int qs = A.sub_samples == 1 ? q : q / A.sub_samples;
+                    const int sample = A.sample_begin + s0 + qs;
+                    const int sub = q - qs * A.sub_samples;
+                    const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
+                    if (col < A.nx && row < A.ny) {
+                        rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
+                        const int j = A.ny - 1 - row;
+                        const float u = (float(col) + rng.next()) * inv_nx;
+                        const float v = (float(j) + rng.next()) * inv_ny;
+                        const V3 disk = S.cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
+                        const float time01 = rng.next();
+                        r = rtf::camera_ray(S.cam, u, v, disk, time01);
+                        T = v3(1, 1, 1);
+                        depth = 0;
+                        alive = true;
+                        fresh = true;
+                    }
+                }
+                next += __popcll(dead);
             }
+            if (fresh) rtf::walk_start(w, r, RT_FLT_MAX, true);
+            if (!__any(alive)) {
+                if (next >= total) break;
+                continue; // only out-of-image pixels were drawn; draw again
+            }
+        }
+        // ---- the walks ------------------------------------------------------------------------------
+        if (w.cur >= 0) rtf::walk_node(S, w, 0.001f, stack);
+        const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
+        if (__popcll(__ballot(at_leaf)) >= RT_LEAF_BATCH || !__any(w.cur >= 0)) {
+            if (at_leaf) rtf::walk_leaf(S, w, r, 0.001f, rng, stack);
         }
     }
 
@@ -463,8 +488,8 @@ __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n,
     sf.p = sf.n = v3(0, 0, 0), sf.u = sf.v = 0.0f;
     if (any) rtf::build_surface_lanes(S, r, t, prim, sf);
     rt_hit o;
-    o.prim_id = any ? S.prims[prim].user_id : -1;
-    o.material = any ? S.prims[prim].material : -1;
+    o.prim_id = any ? S.fprims[prim].user_id : -1;
+    o.material = any ? S.fprims[prim].material : -1;
     o.t = any ? t : 0.0f, o.u = sf.u, o.v = sf.v;
     o.p[0] = sf.p.x, o.p[1] = sf.p.y, o.p[2] = sf.p.z;
     o.normal[0] = sf.n.x, o.normal[1] = sf.n.y, o.normal[2] = sf.n.z;
@@ -617,10 +642,11 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     const bool ordered = rt_order_build(d, order, &tree_depth);
     // no record table: the per-lane fast path, with its own tree (rt_bvh.h) and the light records only
     std::vector<rt_bvh_node> bvh;
+    std::vector<rt_prim> fprims;
     int bvh_depth = 0;
-    const bool lanes_ok = !fast_ok && rt_bvh_build(d, bvh, &bvh_depth) && rt_records_build_lights(d, &tab) != 0;
-    if (!lanes_ok) bvh.clear();
-    part parts[12] = {
+    const bool lanes_ok = !fast_ok && rt_bvh_build(d, bvh, fprims, &bvh_depth) && rt_records_build_lights(d, &tab) != 0;
+    if (!lanes_ok) bvh.clear(), fprims.clear();
+    part parts[13] = {
         {d->entries, sizeof(rt_entry) * (size_t)d->n_entries, 0},
         {d->prims, sizeof(rt_prim) * (size_t)d->n_prims, 0},
         {d->xforms, sizeof(rt_xform) * (size_t)d->n_xforms, 0},
@@ -633,6 +659,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         {tab.user_id, sizeof tab.user_id, 0},
         {order.data(), sizeof(int32_t) * order.size(), 0},
         {bvh.data(), sizeof(rt_bvh_node) * bvh.size(), 0},
+        {fprims.data(), sizeof(rt_prim) * fprims.size(), 0},
     };
     size_t total = 0;
     for (part &p : parts) {
@@ -672,6 +699,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     D.lights = (const int32_t *)(b + parts[7].off);
     D.ord = (const int2 *)(b + parts[10].off);
     D.bvh = lanes_ok ? (const rt_bvh_node *)(b + parts[11].off) : nullptr;
+    D.fprims = lanes_ok ? (const rt_prim *)(b + parts[12].off) : nullptr;
     D.ordered = ordered ? 1 : 0;
     D.n_entries = d->n_entries, D.n_lights = d->n_lights;
     D.cam = d->camera;

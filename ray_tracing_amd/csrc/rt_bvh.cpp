@@ -73,26 +73,32 @@ bool local_box(const rt_scene_desc *d, const rt_prim &p, Box &b)
     }
 }
 
+// a point up an instance chain (innermost wrapper first), src/transforms.h:21, 114-122
+void chain_up_point(const rt_scene_desc *d, int chain, float q[3])
+{
+    const rt_chain &c = d->chains[chain];
+    for (int i = c.count - 1; i >= 0; --i) {
+        const rt_xform &x = d->xforms[c.first + i];
+        if (x.kind == RT_XFORM_TRANSLATE) {
+            q[0] += x.a, q[1] += x.b, q[2] += x.c;
+        } else {
+            const float s = x.a, co = x.b, px = q[0], pz = q[2];
+            q[0] = co * px + s * pz;
+            q[2] = -s * px + co * pz;
+        }
+    }
+}
+
 // box of a primitive in WORLD space: the eight corners go up its instance chain (src/transforms.h:30-52, 69-100)
 bool world_box(const rt_scene_desc *d, const rt_prim &p, Box &out)
 {
     const rt_prim &shape = p.kind == RT_PRIM_MEDIUM ? d->prims[p.first] : p;
     Box l;
     if (!local_box(d, shape, l)) return false;
-    const rt_chain &c = d->chains[shape.chain];
     out.clear();
     for (int corner = 0; corner < 8; ++corner) {
         float q[3] = {corner & 1 ? l.hi[0] : l.lo[0], corner & 2 ? l.hi[1] : l.lo[1], corner & 4 ? l.hi[2] : l.lo[2]};
-        for (int i = c.count - 1; i >= 0; --i) {
-            const rt_xform &x = d->xforms[c.first + i];
-            if (x.kind == RT_XFORM_TRANSLATE) {
-                q[0] += x.a, q[1] += x.b, q[2] += x.c;
-            } else {
-                const float s = x.a, co = x.b, px = q[0], pz = q[2];
-                q[0] = co * px + s * pz;
-                q[2] = -s * px + co * pz;
-            }
-        }
+        chain_up_point(d, shape.chain, q);
         out.add(q);
     }
     // float rounding of the rotation: keep the box conservative
@@ -201,22 +207,44 @@ struct Builder {
 
 } // namespace
 
-bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, int *depth)
+bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::vector<rt_prim> &prims, int *depth)
 {
     nodes.clear();
+    prims.assign(d->prims, d->prims + d->n_prims);
     Builder B;
     B.nodes = &nodes;
     std::vector<char> seen((size_t)d->n_prims, 0);
-    for (int e = 0; e < d->n_entries; ++e) {
-        if ((d->entries[e].b & 255) != RT_ENTRY_LEAF) continue;
-        const int32_t pi = d->entries[e].a;
-        if (seen[pi]) continue; // a one-primitive bvh_node holds its primitive twice (src/bvh.h:98-101)
+    auto add_item = [&](int32_t pi) -> bool {
+        if (seen[pi]) return true; // a one-primitive bvh_node holds its primitive twice (src/bvh.h:98-101)
         seen[pi] = 1;
         Item it;
-        if (!world_box(d, d->prims[pi], it.b)) return false;
+        if (!world_box(d, d->prims[pi], it.b)) return false; // from the ORIGINAL primitive and its chain
         for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (it.b.lo[k] + it.b.hi[k]);
         it.prim = pi;
         B.items.push_back(it);
+        rt_prim &p = prims[pi];
+        if (p.chain != 0 && !(p.flags & RT_PRIM_NEEDS_UV)) { // a rigid chain moves a sphere's centre and nothing else
+            if (p.kind == RT_PRIM_SPHERE) {
+                chain_up_point(d, p.chain, p.f);
+                p.chain = 0;
+            } else if (p.kind == RT_PRIM_MOVING_SPHERE) {
+                chain_up_point(d, p.chain, p.f);
+                chain_up_point(d, p.chain, p.f + 3);
+                p.chain = 0;
+            }
+        }
+        return true;
+    };
+    for (int e = 0; e < d->n_entries; ++e) {
+        if ((d->entries[e].b & 255) != RT_ENTRY_LEAF) continue;
+        const int32_t pi = d->entries[e].a;
+        const rt_prim &p = d->prims[pi];
+        if (p.kind == RT_PRIM_GROUP) {
+            for (int k = 0; k < p.count; ++k)
+                if (!add_item(p.first + k)) return false;
+        } else if (!add_item(pi)) {
+            return false;
+        }
     }
     if (B.items.empty()) return false;
     nodes.reserve(B.items.size());

@@ -27,8 +27,12 @@ typedef struct rt_bvh_node {
     float   hi1[3]; int32_t pad1;
 } rt_bvh_node; /* 64 bytes: four dwordx4 loads from one or two cache lines */
 
-/* Builds the tree over the primitives the entry array names (each once).  Returns false when it cannot (a depth
- * bound it could not keep, non-finite boxes); the caller then has no fast path for large scenes. */
-bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, int *depth);
+/* Builds the tree over the primitives the entry array names (each once; the members of a list -- box faces -- are
+ * items of their own, so a leaf is always one sphere, one rect or one constant_medium).  `prims` receives the
+ * primitive table the tree's leaf references index: a copy of d->prims in which spheres under a rigid instance chain
+ * are moved to world space (chain 0; not those whose texture reads (u,v), which is defined in the sphere's own frame).
+ * Returns false when it cannot (a depth bound it could not keep, non-finite boxes); the caller then has no fast
+ * path for large scenes. */
+bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::vector<rt_prim> &prims, int *depth);
 
 #endif

@@ -71,7 +71,7 @@ RTF_DEV bool simple_t(const DevScene &S, int idx, const rt_prim &pr, const Ray &
     float closest = t_max;
     for (int k = 0; k < pr.count; ++k) {
         float ct;
-        if (plain_t(S.prims[pr.first + k], lr, inv, dd, inv_dd, t_min, closest, ct)) {
+        if (plain_t(S.fprims[pr.first + k], lr, inv, dd, inv_dd, t_min, closest, ct)) {
             h = true;
             closest = ct;
             t = ct, which = pr.first + k;
@@ -80,102 +80,124 @@ RTF_DEV bool simple_t(const DevScene &S, int idx, const rt_prim &pr, const Ray &
     return h;
 }
 
-// world->hit() over the library's own tree (rt_bvh.h): closest t and the primitive that gave it (a MEDIUM
-// primitive for a hit inside a constant_medium).  Boxes are in world space; a leaf under an instance chain
-// takes the ray down its chain (src/transforms.h:17, 107-110) when the lane gets there.
+// ---------------------------------------------------------------------------
+// world->hit() over the library's own tree (rt_bvh.h), as a per-lane state machine.
+// A lane's walk is (cur, sp, best_t, best_prim): cur >= 0 an inner node to open, cur < 0 a leaf to test
+// (~cur is the rt_prim index), RT_BVH_NONE when the walk is over.  The steps below advance the lanes that are in
+// the matching state; the callers decide how to interleave them (hit_bvh: one ray per lane until every lane is
+// done; render_fastlanes_kernel: lanes that finish are shaded and restarted while the others keep walking).
+// Boxes are in world space; a leaf under an instance chain takes the ray down its chain
+// (src/transforms.h:17, 107-110) when the lane gets there.
+// ---------------------------------------------------------------------------
+struct Walk {
+    int cur, sp;
+    float best_t;
+    int best_prim; // a MEDIUM primitive for a hit inside a constant_medium
+    V3 winv, noi;  // 1/d and -o/d: t = lo * winv + noi, one FMA per plane.  Where 1/d overflows the two terms can
+                   // cancel to NaN; min/max drop a NaN, which only ever makes a box easier to enter.
+    float dd, inv_dd; // d.d (chains are rigid: the same in every space)
+};
+RTF_DEV void walk_start(Walk &w, const Ray &wr, float t_max, bool go)
+{
+    w.cur = go ? 0 : RT_BVH_NONE;
+    w.sp = 0;
+    w.best_t = t_max;
+    w.best_prim = -1;
+    w.winv = rcp3(wr.d);
+    w.noi = v3(-wr.o.x * w.winv.x, -wr.o.y * w.winv.y, -wr.o.z * w.winv.z);
+    w.dd = fdot(wr.d, wr.d);
+    w.inv_dd = rcp(w.dd);
+}
+RTF_DEV int walk_pop(Walk &w, const int *stack) { return w.sp > 0 ? stack[--w.sp * 64] : RT_BVH_NONE; }
+
+// lanes with cur >= 0: both children's boxes of node cur, far bound = best hit so far; nearer child next, the other pushed
+RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, int *stack)
+{
+    const uint4 *q = reinterpret_cast<const uint4 *>(S.bvh + w.cur);
+    const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+    const V3 i = w.winv, n = w.noi;
+    const float x00 = fmaf(__uint_as_float(a0.x), i.x, n.x), x01 = fmaf(__uint_as_float(a1.x), i.x, n.x);
+    const float y00 = fmaf(__uint_as_float(a0.y), i.y, n.y), y01 = fmaf(__uint_as_float(a1.y), i.y, n.y);
+    const float z00 = fmaf(__uint_as_float(a0.z), i.z, n.z), z01 = fmaf(__uint_as_float(a1.z), i.z, n.z);
+    const float x10 = fmaf(__uint_as_float(a2.x), i.x, n.x), x11 = fmaf(__uint_as_float(a3.x), i.x, n.x);
+    const float y10 = fmaf(__uint_as_float(a2.y), i.y, n.y), y11 = fmaf(__uint_as_float(a3.y), i.y, n.y);
+    const float z10 = fmaf(__uint_as_float(a2.z), i.z, n.z), z11 = fmaf(__uint_as_float(a3.z), i.z, n.z);
+    const float tn0 = fmaxf(fmax3(fminf(x00, x01), fminf(y00, y01), fminf(z00, z01)), t_min);
+    const float tf0 = fminf(fmin3(fmaxf(x00, x01), fmaxf(y00, y01), fmaxf(z00, z01)), w.best_t);
+    const float tn1 = fmaxf(fmax3(fminf(x10, x11), fminf(y10, y11), fminf(z10, z11)), t_min);
+    const float tf1 = fminf(fmin3(fmaxf(x10, x11), fmaxf(y10, y11), fmaxf(z10, z11)), w.best_t);
+    const int ref0 = (int)a0.w, ref1 = (int)a1.w;
+    const bool h0 = tf0 >= tn0, h1 = (tf1 >= tn1) & (ref1 != RT_BVH_NONE);
+    const bool first0 = tn0 <= tn1;
+    const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
+    const bool hn = first0 ? h0 : h1, hf = first0 ? h1 : h0;
+    if (hn & hf) {
+        stack[w.sp++ * 64] = far;
+        w.cur = near;
+    } else if (hn | hf) {
+        w.cur = hn ? near : far;
+    } else {
+        w.cur = walk_pop(w, stack);
+    }
+}
+
+// lanes with cur < 0 (and not NONE): primitive ~cur against the lane's ray
+RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, int *stack)
+{
+    const int leaf = ~w.cur;
+    const rt_prim &pr = S.fprims[leaf];
+    const int chain = pr.kind == RT_PRIM_MEDIUM ? S.fprims[pr.first].chain : pr.chain;
+    Ray lr = wr;
+    V3 inv = w.winv;
+    if (chain != 0) {
+        lr = rt::chain_down(S, chain, wr);
+        inv = rcp3(lr.d);
+    }
+    float t = 0.0f;
+    int which = leaf;
+    bool h;
+    if (pr.kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment)
+        const rt_prim &bp = S.fprims[pr.first];
+        float t1 = 0.0f, t2 = 0.0f;
+        int dummy;
+        h = false;
+        if (simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
+            simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy)) {
+            t1 = fminf(fmaxf(t1, t_min), w.best_t);
+            if (t1 < t2) {
+                t1 = fmaxf(t1, 0.0f);
+                const float hit_distance = -rcp(pr.f[0]) * __logf(rng.next());
+                t = fmaf(hit_distance, rsq(w.dd), t1);
+                h = true;
+            }
+        }
+    } else {
+        h = simple_t(S, leaf, pr, lr, inv, w.dd, w.inv_dd, t_min, w.best_t, t, which);
+    }
+    const bool take = h & (t <= w.best_t);
+    w.best_t = take ? t : w.best_t;
+    w.best_prim = take ? which : w.best_prim;
+    w.cur = walk_pop(w, stack);
+}
+
+// one ray per lane, to the end
 RTF_DEV bool hit_bvh(const DevScene &S, const Ray &wr, float t_min, float t_max, bool alive, Rng &rng, float &best_t, int &best_prim,
                      int *stack)
 {
-    best_t = t_max;
-    best_prim = -1;
-    int sp = 0;
-    int cur = alive ? 0 : RT_BVH_NONE;
-    const V3 winv = rcp3(wr.d);
-    // t = lo * inv - o * inv, one FMA per plane.  Where 1/d overflows the two terms can cancel to NaN; min/max drop a
-    // NaN, which only ever makes a box easier to enter.
-    const V3 noi = v3(-wr.o.x * winv.x, -wr.o.y * winv.y, -wr.o.z * winv.z);
-    int cur_chain = 0;
-    Ray lr = wr;
-    V3 inv = winv;
-    const float dd = fdot(wr.d, wr.d), inv_dd = rcp(dd); // chains are rigid: d.d is the same in every space
-
-    while (__any(cur != RT_BVH_NONE)) {
-        while (cur >= 0) { // inner node: both children's boxes, far bound = best hit so far
-            const uint4 *q = reinterpret_cast<const uint4 *>(S.bvh + cur);
-            const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-            const float tn0 = fmaxf(fmax3(fminf(fmaf(__uint_as_float(a0.x), winv.x, noi.x), fmaf(__uint_as_float(a1.x), winv.x, noi.x)),
-                                          fminf(fmaf(__uint_as_float(a0.y), winv.y, noi.y), fmaf(__uint_as_float(a1.y), winv.y, noi.y)),
-                                          fminf(fmaf(__uint_as_float(a0.z), winv.z, noi.z), fmaf(__uint_as_float(a1.z), winv.z, noi.z))),
-                                    t_min);
-            const float tf0 = fminf(fmin3(fmaxf(fmaf(__uint_as_float(a0.x), winv.x, noi.x), fmaf(__uint_as_float(a1.x), winv.x, noi.x)),
-                                          fmaxf(fmaf(__uint_as_float(a0.y), winv.y, noi.y), fmaf(__uint_as_float(a1.y), winv.y, noi.y)),
-                                          fmaxf(fmaf(__uint_as_float(a0.z), winv.z, noi.z), fmaf(__uint_as_float(a1.z), winv.z, noi.z))),
-                                    best_t);
-            const float tn1 = fmaxf(fmax3(fminf(fmaf(__uint_as_float(a2.x), winv.x, noi.x), fmaf(__uint_as_float(a3.x), winv.x, noi.x)),
-                                          fminf(fmaf(__uint_as_float(a2.y), winv.y, noi.y), fmaf(__uint_as_float(a3.y), winv.y, noi.y)),
-                                          fminf(fmaf(__uint_as_float(a2.z), winv.z, noi.z), fmaf(__uint_as_float(a3.z), winv.z, noi.z))),
-                                    t_min);
-            const float tf1 = fminf(fmin3(fmaxf(fmaf(__uint_as_float(a2.x), winv.x, noi.x), fmaf(__uint_as_float(a3.x), winv.x, noi.x)),
-                                          fmaxf(fmaf(__uint_as_float(a2.y), winv.y, noi.y), fmaf(__uint_as_float(a3.y), winv.y, noi.y)),
-                                          fmaxf(fmaf(__uint_as_float(a2.z), winv.z, noi.z), fmaf(__uint_as_float(a3.z), winv.z, noi.z))),
-                                    best_t);
-            const int ref0 = (int)a0.w, ref1 = (int)a1.w;
-            const bool h0 = tf0 >= tn0, h1 = (tf1 >= tn1) & (ref1 != RT_BVH_NONE);
-            const bool first0 = tn0 <= tn1;
-            const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
-            const bool hn = first0 ? h0 : h1, hf = first0 ? h1 : h0;
-            if (hn & hf) {
-                stack[sp++ * 64] = far;
-                cur = near;
-            } else if (hn | hf) {
-                cur = hn ? near : far;
-            } else {
-                cur = sp > 0 ? stack[--sp * 64] : RT_BVH_NONE;
-            }
-        }
-        if (cur != RT_BVH_NONE) { // a leaf
-            const int leaf = ~cur;
-            const rt_prim &pr = S.prims[leaf];
-            const int chain = pr.kind == RT_PRIM_MEDIUM ? S.prims[pr.first].chain : pr.chain;
-            if (chain != cur_chain) {
-                lr = rt::chain_down(S, chain, wr);
-                inv = rcp3(lr.d);
-                cur_chain = chain;
-            }
-            float t = 0.0f;
-            int which = leaf;
-            bool h;
-            if (pr.kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment)
-                const rt_prim &bp = S.prims[pr.first];
-                float t1 = 0.0f, t2 = 0.0f;
-                int dummy;
-                h = false;
-                if (simple_t(S, pr.first, bp, lr, inv, dd, inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
-                    simple_t(S, pr.first, bp, lr, inv, dd, inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy)) {
-                    t1 = fminf(fmaxf(t1, t_min), best_t);
-                    if (t1 < t2) {
-                        t1 = fmaxf(t1, 0.0f);
-                        const float hit_distance = -rcp(pr.f[0]) * __logf(rng.next());
-                        t = fmaf(hit_distance, rsq(dd), t1);
-                        h = true;
-                    }
-                }
-            } else {
-                h = simple_t(S, leaf, pr, lr, inv, dd, inv_dd, t_min, best_t, t, which);
-            }
-            const bool take = h & (t <= best_t);
-            best_t = take ? t : best_t;
-            best_prim = take ? which : best_prim;
-            cur = sp > 0 ? stack[--sp * 64] : RT_BVH_NONE;
-        }
+    Walk w;
+    walk_start(w, wr, t_max, alive);
+    while (__any(w.cur != RT_BVH_NONE)) {
+        while (w.cur >= 0) walk_node(S, w, t_min, stack);
+        if (w.cur != RT_BVH_NONE) walk_leaf(S, w, wr, t_min, rng, stack);
     }
+    best_t = w.best_t, best_prim = w.best_prim;
     return best_prim >= 0;
 }
 
 // point, normal, (u,v), material of the winner; every lane for itself
 RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int prim, Surface &s)
 {
-    const rt_prim &pr = S.prims[prim < 0 ? 0 : prim];
+    const rt_prim &pr = S.fprims[prim < 0 ? 0 : prim];
     s.p = fma3(t, wr.d, wr.o);
     s.u = s.v = 0.0f;
     const int kind = pr.kind;
