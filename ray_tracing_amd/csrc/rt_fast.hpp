@@ -307,41 +307,27 @@ RTF_DEV float lights_pdf_value(const uint32_t *__restrict__ recs, const Layout &
     }
     return sum;
 }
-// hitable_list::random, src/hitable_list.h:79-88: the member is chosen per lane
-RTF_DEV V3 lights_random(const uint32_t *__restrict__ recs, const Layout &Y, V3 o, Rng &rng)
+// hitable_list::random, src/hitable_list.h:79-88, first half: the member is chosen per lane.  The (few) light
+// records are read with wave-uniform scalar loads and each lane keeps the one it drew.  (ds_bpermute from the
+// register-resident table must not be used here: under a divergent branch it returns 0 for records held by
+// inactive lanes.)
+struct LightPick {
+    uint32_t kind;
+    float f0, f1, f2, f3, f4;
+};
+RTF_DEV LightPick lights_pick(const uint32_t *__restrict__ recs, const Layout &Y, Rng &rng)
 {
     int index = (int)(rng.next() * (float)Y.n_lights);
     if (index == Y.n_lights) index--;
-    // The member is chosen per lane; the (few) light records are read with wave-uniform scalar loads
-    // and each lane keeps the one it drew.  (ds_bpermute from the register-resident table must not be
-    // used here: under a divergent branch it returns 0 for records held by inactive lanes.)
-    uint32_t kind = RT_REC_LIGHT_NONE;
-    float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f, f3 = 0.0f, f4 = 0.0f;
+    LightPick p{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int k = 0; k < Y.n_lights; ++k) {
         const SRec c = load_rec(recs, Y.lights_base + k);
         const bool mine = index == k;
-        kind = mine ? (c.d[7] & 15u) : kind;
-        f0 = mine ? sf(c, 0) : f0, f1 = mine ? sf(c, 1) : f1, f2 = mine ? sf(c, 2) : f2;
-        f3 = mine ? sf(c, 3) : f3, f4 = mine ? sf(c, 4) : f4;
+        p.kind = mine ? (c.d[7] & 15u) : p.kind;
+        p.f0 = mine ? sf(c, 0) : p.f0, p.f1 = mine ? sf(c, 1) : p.f1, p.f2 = mine ? sf(c, 2) : p.f2;
+        p.f3 = mine ? sf(c, 3) : p.f3, p.f4 = mine ? sf(c, 4) : p.f4;
     }
-    if (kind == RT_REC_LIGHT_RECT) { // xz_rect::random, src/plane.h:94-98 (z takes the first draw)
-        const float rz = rng.next(), rx = rng.next();
-        return v3(fmaf(rx, f1 - f0, f0) - o.x, f4 - o.y, fmaf(rz, f3 - f2, f2) - o.z);
-    }
-    if (kind == RT_REC_LIGHT_SPHERE) { // sphere::random + random_to_sphere, src/sphere.h:85-103
-        const V3 direction = v3(f0 - o.x, f1 - o.y, f2 - o.z);
-        const float distance_squared = fdot(direction, direction);
-        Onb uvw;
-        uvw.build_from_w(direction);
-        const float r1 = rng.next();
-        const float r2 = rng.next();
-        const float z = fmaf(r2, fsqrt(1.0f - f3 * f3 * rcp(distance_squared)) - 1.0f, 1.0f);
-        float s, c;
-        sincos_2pi(r1, s, c);
-        const float q = fsqrt(1.0f - z * z);
-        return uvw.local(v3(c * q, s * q, z));
-    }
-    return v3(1, 0, 0); // hitable::random, src/hitable.h:20
+    return p;
 }
 
 // One bounce of color() (src/main.cpp:91-127) in throughput form; see rt::shade for the derivation.
@@ -361,20 +347,41 @@ RTF_DEV bool shade(const DevScene &S, const uint32_t *__restrict__ recs, const L
     if (!(depth < max_depth)) return false;
     ++depth;
     if (h.mat_kind == RT_MAT_LAMBERTIAN) {
-        Onb uvw;
-        uvw.build_from_w(h.n);
-        V3 dir;
-        if (rng.next() < 0.5f) {
-            dir = funit(lights_random(recs, Y, h.p, rng));
-        } else { // cosine_pdf::generate with random_cosine_direction's factor 2 (src/vec3.h:179-180)
+        // mixture_pdf::generate (src/pdf.h:71-79): half the lanes sample the important list, half the cosine lobe.
+        // A sphere light (sphere::random + random_to_sphere, src/sphere.h:85-103) and the cosine lobe
+        // (cosine_pdf::generate, random_cosine_direction with its factor 2, src/vec3.h:179-180) are the same
+        // computation around different axes -- an orthonormal basis, two draws, a point on a cap -- so those lanes
+        // run it together; a rect light (xz_rect::random, src/plane.h:94-98, z takes the first draw) needs no basis.
+        const V3 wn = funit(h.n);
+        const bool to_light = rng.next() < 0.5f;
+        LightPick lp{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (to_light) lp = lights_pick(recs, Y, rng);
+        V3 dir = v3(1, 0, 0); // hitable::random, src/hitable.h:20
+        if (to_light & (lp.kind == RT_REC_LIGHT_RECT)) {
+            const float rz = rng.next(), rx = rng.next();
+            dir = v3(fmaf(rx, lp.f1 - lp.f0, lp.f0) - h.p.x, lp.f4 - h.p.y, fmaf(rz, lp.f3 - lp.f2, lp.f2) - h.p.z);
+        }
+        const bool sphere_light = to_light & (lp.kind == RT_REC_LIGHT_SPHERE);
+        if (!to_light | sphere_light) {
+            const V3 axis = sphere_light ? v3(lp.f0 - h.p.x, lp.f1 - h.p.y, lp.f2 - h.p.z) : wn;
+            Onb uvw;
+            uvw.build_from_w(axis);
             const float r1 = rng.next();
             const float r2 = rng.next();
             float s, c;
             sincos_2pi(r1, s, c);
-            const float q = 2.0f * fsqrt(r2);
-            dir = funit(uvw.local(v3(c * q, s * q, fsqrt(1.0f - r2))));
+            float z, q;
+            if (sphere_light) {
+                z = fmaf(r2, fsqrt(1.0f - lp.f3 * lp.f3 * rcp(fdot(axis, axis))) - 1.0f, 1.0f);
+                q = fsqrt(1.0f - z * z);
+            } else {
+                z = fsqrt(1.0f - r2);
+                q = 2.0f * fsqrt(r2);
+            }
+            dir = uvw.local(v3(c * q, s * q, z));
         }
-        const float cosine = fdot(dir, uvw.w);
+        dir = funit(dir);
+        const float cosine = fdot(dir, wn);
         const float cos_val = cosine > 0.0f ? cosine * (1.0f / RT_PI) : 0.0f;
         const float pdf_val = 0.5f * lights_pdf_value(recs, Y, h.p, dir) + 0.5f * cos_val;
         const float sc = fmaxf(fdot(h.n, dir), 0.0f) * (1.0f / RT_PI);
