@@ -415,6 +415,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fastlanes_kernel(
             if (waiting) {
                 const bool hit_any = w.best_prim >= 0;
                 rtf::Surface sf;
+                sf.p = r.o; // a miss ends the path; shade still writes the (dead) ray from it
                 if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
                 V3 L;
                 if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
