@@ -215,8 +215,15 @@ bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::
     B.nodes = &nodes;
     std::vector<char> seen((size_t)d->n_prims, 0);
     auto add_item = [&](int32_t pi) -> bool {
-        if (seen[pi]) return true; // a one-primitive bvh_node holds its primitive twice (src/bvh.h:98-101)
+        // A one-primitive bvh_node holds its primitive twice (src/bvh.h:98-101) and the reference visits it twice.  For a
+        // surface that changes nothing; a constant_medium draws a random number per visit (src/volume.h:43), so it gets
+        // two chances to scatter.  The item is stored once, with the number of visits (rt_prim.reserved) for walk_leaf.
+        if (seen[pi]) {
+            ++prims[pi].reserved;
+            return true;
+        }
         seen[pi] = 1;
+        prims[pi].reserved = 1;
         Item it;
         if (!world_box(d, d->prims[pi], it.b)) return false; // from the ORIGINAL primitive and its chain
         for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (it.b.lo[k] + it.b.hi[k]);

@@ -166,7 +166,11 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
             t1 = fminf(fmaxf(t1, t_min), w.best_t);
             if (t1 < t2) {
                 t1 = fmaxf(t1, 0.0f);
-                const float hit_distance = -rcp(pr.f[0]) * __logf(rng.next());
+                // one draw per visit the reference pays this medium (rt_bvh.cpp: a lone child of a bvh_node is visited
+                // twice); the nearest of the candidates is what its tree keeps
+                float u = rng.next();
+                for (int v = 1; v < pr.reserved; ++v) u = fmaxf(u, rng.next());
+                const float hit_distance = -rcp(pr.f[0]) * __logf(u);
                 t = fmaf(hit_distance, rsq(w.dd), t1);
                 h = true;
             }

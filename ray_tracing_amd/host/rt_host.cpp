@@ -54,6 +54,9 @@ const named_scene k_scenes[] = {
     {"cornell_box_volumes", cornell_box_volumes},
     {"random_spheres", random_spheres},
     {"next_week_final", next_week_final},
+    {"simple_scene", simple_scene},
+    {"another_simple", another_simple},
+    {"two_perlin_spheres", two_perlin_spheres},
     {"sphere_field_4k", sphere_field_4k},
     {"sphere_field_1m", sphere_field_1m},
 };

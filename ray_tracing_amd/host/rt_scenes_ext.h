@@ -154,6 +154,82 @@ inline void next_week_final(hitable **scene, hitable **important_hitables, camer
                       800.0f, 0.0f, 1.0f);
 }
 
+// src/scenes.h:90-107 -- "simple scene": glass, earth-textured and metal spheres under a sphere light and a small rect light
+inline void simple_scene(hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    int nx = 0, ny = 0;
+    unsigned char *tex_data = rt_ext_earth_pixels(&nx, &ny);
+    hitable **list = new hitable *[10];
+    int i = 0;
+    // DECISION: the ground carries the checker texture the reference keeps in a comment two lines below (src/scenes.h:101);
+    // no other scene of the reference uses checker_texture
+    list[i++] = new sphere(vec3(0, -1000, 0), 1000,
+                           new lambertian(new checker_texture(new constant_texture(vec3(0.4f, 0.2f, 0.1f)),
+                                                              new constant_texture(vec3(0.9f, 0.9f, 0.9f)))));
+    list[i++] = new sphere(vec3(4.0f, 1.0f, 0.0f), 1.0f, new dielectric(1.5f));
+    if (tex_data) list[i++] = new sphere(vec3(0.0f, 1.0f, 0.0f), 1.0f, new lambertian(new image_texture(tex_data, nx, ny)));
+    list[i++] = new sphere(vec3(-4.0f, 1.0f, 0.0f), 1.0f, new metal(new constant_texture(vec3(0.7f, 0.6f, 0.5f)), 0.0f));
+    hitable *lamp = new sphere(vec3(0, 6, 0), 3, new diffuse_light(new constant_texture(vec3(4, 4, 3))));
+    list[i++] = lamp;
+    list[i++] = new xy_rect(3, 5, 1, 3, -2, new diffuse_light(new constant_texture(vec3(4, 4, 4))));
+    hitable **imp = new hitable *[1];
+    imp[0] = lamp; // DECISION: the sphere lamp (an xy_rect has no pdf_value/random, src/plane.h:9-29)
+    *important_hitables = new hitable_list(imp, 1);
+    *scene = new hitable_list(list, i);
+    // DECISION: the book's camera for its sphere scenes
+    *cam = new camera(vec3(13.0f, 2.0f, 3.0f), vec3(0.0f, 1.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f), 30.0f, aspect, 0.0f, 10.0f, 0.0f, 1.0f);
+}
+
+// src/scenes.h:112-146 -- "another simple": 25 glass spheres filled with media of rising density and index, under a white sky
+inline void another_simple(hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    int l = 0;
+    hitable **list = new hitable *[100];
+    list[l++] = new flip_normals(new sphere(vec3(0, 0, 0), 50, new diffuse_light(new constant_texture(vec3(1, 1, 1)))));
+    list[l++] = new sphere(vec3(0, -1000, 0), 1000, new lambertian(new constant_texture(vec3(0.5f, 0.5f, 0.5f))));
+    const float sphere_height = 17.0f;
+    const float sphere_radius = 1.0f;
+    const float diameter = 2.0f * sphere_radius;
+    const int nb = 5;
+    const float half_scene_size = (nb * diameter) / 2.0f;
+    hitable *middle = nullptr;
+    for (int i = 0; i < nb; ++i) {
+        for (int j = 0; j < nb; ++j) {
+            vec3 position(i * diameter - half_scene_size + sphere_radius, sphere_height, j * diameter - half_scene_size + sphere_radius);
+            float density = (nb - j) * 1.0f;
+            float ior = 1.0f + (i + 1) * 0.1f;
+            hitable *boundary = new sphere(position, 1.0f, new dielectric(ior));
+            if (i == nb / 2 && j == nb / 2) middle = boundary;
+            list[l++] = boundary;
+            list[l++] = new constant_medium(boundary, density, new constant_texture(vec3(0.2f, 0.4f, 0.9f)));
+        }
+    }
+    hitable **imp = new hitable *[1];
+    imp[0] = middle; // DECISION: the sky is a flip_normals wrapper (no pdf_value/random, src/hitable.h:27-38); the list
+                     // samples the middle glass sphere, as the live cornell_box samples its glass sphere
+    *important_hitables = new hitable_list(imp, 1);
+    *scene = new hitable_list(list, l);
+    // DECISION: a camera below the grid, looking up at it
+    *cam = new camera(vec3(0.0f, 3.0f, -18.0f), vec3(0.0f, 15.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect, 0.0f, 10.0f, 0.0f, 1.0f);
+}
+
+// src/scenes.h:151-160 -- two spheres with the perlin texture
+inline void two_perlin_spheres(hitable **scene, hitable **important_hitables, camera **cam, float aspect)
+{
+    texture *pertex = new noise_texture(2.0f);
+    hitable **list = new hitable *[3];
+    list[0] = new sphere(vec3(0, -1000, 0), 1000, new lambertian(pertex));
+    list[1] = new sphere(vec3(0.0f, 2.0f, 0.0f), 2.0f, new lambertian(pertex));
+    // DECISION: the old function has no emitter and a miss is black (src/main.cpp:125): a sphere lamp, the important list
+    hitable *lamp = new sphere(vec3(0, 7, 0), 2, new diffuse_light(new constant_texture(vec3(4, 4, 4))));
+    list[2] = lamp;
+    hitable **imp = new hitable *[1];
+    imp[0] = lamp;
+    *important_hitables = new hitable_list(imp, 1);
+    *scene = new hitable_list(list, 3);
+    *cam = new camera(vec3(13.0f, 2.0f, 3.0f), vec3(0.0f, 2.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f), 30.0f, aspect, 0.0f, 10.0f, 0.0f, 1.0f);
+}
+
 // BASELINE.json config 5: "procedural 1M-sphere scene (deep BVH, incoherent secondary rays)".  The reference holds no
 // such scene; this one is written in its style so that the reference's own code can render it too (the harness does, at
 // 4096 spheres, for the golden vectors).  DECISION, all of it: n spheres of radius 0.25 with centres uniform in a cube of
@@ -209,6 +285,9 @@ inline rt_ext_scene_fn rt_extra_scene(const char *name)
     if (!strcmp(name, "cornell_box_volumes")) return cornell_box_volumes;
     if (!strcmp(name, "random_spheres")) return random_spheres;
     if (!strcmp(name, "next_week_final")) return next_week_final;
+    if (!strcmp(name, "simple_scene")) return simple_scene;
+    if (!strcmp(name, "another_simple")) return another_simple;
+    if (!strcmp(name, "two_perlin_spheres")) return two_perlin_spheres;
     if (!strcmp(name, "sphere_field_4k")) return sphere_field_4k;
     if (!strcmp(name, "sphere_field_1m")) return sphere_field_1m;
     return nullptr;

@@ -262,7 +262,8 @@ def test_psnr_against_the_converged_reference_and_why_40_db_is_out_of_reach():
 
 # ---- scenes beyond the Cornell box (ray_tracing_amd/host/rt_scenes_ext.h): media, moving spheres, textures, lens,
 # ---- nested BVHs under instance chains.  They run on the exact path (the record table is for small static scenes).
-EXT = ["cornell_box_volumes", "random_spheres", "next_week_final", "sphere_field_4k"]
+EXT = ["cornell_box_volumes", "random_spheres", "next_week_final", "sphere_field_4k", "simple_scene", "another_simple",
+       "two_perlin_spheres"]
 
 
 @pytest.mark.parametrize("scene", EXT)
@@ -271,7 +272,8 @@ def test_ext_scene_trace_equals_oracle_and_reference(scene):
     hs = HostScene(scene, 64 / 48)
     sc = Scene(hs, 0)
     # too large (or too rich) for the record table; the fast path for them is the per-lane one (rt_fastlanes.hpp)
-    assert sc.info(_capi.RT_INFO_RECORDS) == -1 and sc.info(_capi.RT_INFO_FAST_PATH_AVAILABLE) == 1
+    assert sc.info(_capi.RT_INFO_FAST_PATH_AVAILABLE) == 1
+    assert (sc.info(_capi.RT_INFO_RECORDS) > 0) == (scene == "two_perlin_spheres")  # the only one small and plain enough
     rays = tab[:, 2:9].copy()
     g, c = api.trace_rays(sc, rays, seed=5), O.trace_rays(hs, rays, seed=5)
     sc.close()
@@ -301,7 +303,8 @@ def test_ext_scene_trace_equals_oracle_and_reference(scene):
         assert uv.sum() > 10
 
 
-@pytest.mark.parametrize("scene,nx,ny,ns", [("cornell_box_volumes", 32, 24, 8), ("random_spheres", 48, 32, 4), ("next_week_final", 32, 24, 4), ("sphere_field_4k", 32, 24, 4)])
+@pytest.mark.parametrize("scene,nx,ny,ns", [("cornell_box_volumes", 32, 24, 8), ("random_spheres", 48, 32, 4), ("next_week_final", 32, 24, 4), ("sphere_field_4k", 32, 24, 4),
+                                                ("simple_scene", 32, 24, 4), ("another_simple", 32, 24, 4), ("two_perlin_spheres", 32, 24, 4)])
 def test_ext_scene_render_matches_oracle_on_the_same_stream(scene, nx, ny, ns):
     """Same tolerance as on the Cornell box; these scenes add logf / sinf / atan2f (media, perlin, image uv) on the way,
     so a few more paths diverge: >= 93 % of pixels within 1e-3, image mean within 3 %."""
@@ -327,10 +330,12 @@ def test_ext_scene_fast_trace_close_to_exact(scene):
     sc = Scene(hs, 0)
     rng = np.random.default_rng(17)
     n = 20000
-    lo, hi = (-8.0, 8.0) if scene in ("random_spheres", "sphere_field_4k") else (0.0, 555.0)
+    lo, hi = (0.0, 555.0) if scene in ("cornell_box_volumes", "next_week_final") else (-8.0, 8.0)
     o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
-    if scene == "random_spheres":
-        o[:, 1] = np.abs(o[:, 1]) * 0.5 + 0.05
+    if scene in ("random_spheres", "simple_scene", "two_perlin_spheres"):
+        o[:, 1] = np.abs(o[:, 1]) * 0.5 + 0.05  # above the ground sphere
+    if scene == "another_simple":
+        o[:, 1] = 17.0 + o[:, 1] * 0.5
     if scene == "next_week_final":
         # above the ground boxes (height <= 101): neighbouring boxes share walls, and a ray that starts INSIDE one meets two
         # coincident faces at the same t, where the two walks are free to pick different winners (ties: rt_fastlanes.hpp)
@@ -364,7 +369,8 @@ def test_ext_scene_fast_trace_close_to_exact(scene):
     assert abs(em.mean() - fm.mean()) < 0.02
 
 
-@pytest.mark.parametrize("scene,nx,ny,spp", [("cornell_box_volumes", 64, 64, 64), ("random_spheres", 96, 64, 64), ("next_week_final", 64, 64, 32), ("sphere_field_4k", 64, 64, 64)])
+@pytest.mark.parametrize("scene,nx,ny,spp", [("cornell_box_volumes", 64, 64, 64), ("random_spheres", 96, 64, 64), ("next_week_final", 64, 64, 32), ("sphere_field_4k", 64, 64, 64),
+                                                 ("simple_scene", 64, 64, 64), ("another_simple", 64, 64, 64), ("two_perlin_spheres", 64, 64, 64)])
 def test_ext_scene_fast_render_statistics(scene, nx, ny, spp):
     """The per-lane fast path (what AUTO picks for trees above 64 entries).  Its image is an independent unbiased estimate of the same
     integral as the exact path's: per-channel image means agree within 3 standard errors (estimated from 8 batches per path)."""

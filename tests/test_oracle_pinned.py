@@ -211,7 +211,8 @@ def test_counter_mode_is_thread_count_invariant(cornell_host):
 # The same scene source is compiled against the reference's headers inside oracle/_ref/ref_harness, which wrote
 # the fixtures with the reference's own hit()/color(); they exercise moving spheres, media, perlin / image
 # textures, metal fuzz, a lens, nested BVHs under translate(rotate_y()).
-EXT = ["cornell_box_volumes", "random_spheres", "next_week_final", "sphere_field_4k"]
+EXT = ["cornell_box_volumes", "random_spheres", "next_week_final", "sphere_field_4k", "simple_scene", "another_simple",
+       "two_perlin_spheres"]
 
 
 @pytest.mark.parametrize("scene", EXT)
