@@ -13,13 +13,16 @@
 //   * -p writes the normal / depth / uv passes the reference describes in its disabled pre-pass
 //     (src/main.cpp:270-326) from rt_camera_rays + rt_trace_rays at pixel centres; the reference's own -p
 //     dumps buffers it never fills;
-//   * extra options, absent from the reference: --scene NAME, --seed N, --device N, --path auto|exact|fast.
+//   * extra options, absent from the reference: --scene NAME, --seed N, --device N, --path auto|exact|fast, and
+//     --accum FILE [--save-every N]: progressive render with save and resume, which the reference lists as not done
+//     (TODO.txt:5-17).  The file holds the float sums and the number of samples in them; -s is the TOTAL wanted.
 // No CPU rendering path exists here: without a HIP device the program stops with the library's error.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -64,6 +67,8 @@ Opt g_opts[] = {
     {"", "seed", "Seed of the per-path random numbers", false, "1", nullptr, "", 0},
     {"", "device", "HIP device ordinal", false, "0", nullptr, "", 0},
     {"", "path", "auto | exact | fast", true, "auto", nullptr, "", 0},
+    {"", "accum", "Accumulator file: resume from it if it exists, save to it", true, "", nullptr, "", 0},
+    {"", "save-every", "With --accum: also save after every N samples", false, "0", nullptr, "", 0},
 };
 const int g_nopts = sizeof(g_opts) / sizeof(g_opts[0]);
 
@@ -233,6 +238,49 @@ void check(int rc, const char *what)
 
 std::string base_name(const std::string &out) { return out.substr(0, out.find_last_of(".")); }
 
+// ---------------------------------------------------------------- accumulator file (--accum)
+// The sums of rt_render ([A, B, G, R] per pixel, A = samples) with what they were rendered with.  Sample indices
+// [0, samples) are in the file; a resumed run renders [samples, -s) with the same seed, so the image does not depend
+// on where a run was interrupted (only float summation order does).
+struct AccumHeader {
+    char magic[8]; // "RTACC1\0\0"
+    int32_t nx, ny, samples, sub_samples, max_depth;
+    uint32_t seed;
+    char scene[40];
+};
+AccumHeader accum_header(int nx, int ny, int samples, int nss, int depth, uint32_t seed, const std::string &scene)
+{
+    AccumHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "RTACC1", 6);
+    h.nx = nx, h.ny = ny, h.samples = samples, h.sub_samples = nss, h.max_depth = depth, h.seed = seed;
+    strncpy(h.scene, scene.c_str(), sizeof h.scene - 1);
+    return h;
+}
+// returns the number of samples in the file (0 if there is no file); dies if the file is for another render
+int load_accum(const std::string &path, const AccumHeader &want, std::vector<float> &sums)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return 0;
+    AccumHeader h;
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, want.magic, 8) && h.nx == want.nx && h.ny == want.ny &&
+              h.sub_samples == want.sub_samples && h.max_depth == want.max_depth && h.seed == want.seed &&
+              !strncmp(h.scene, want.scene, sizeof h.scene) && h.samples >= 0;
+    ok = ok && fread(sums.data(), sizeof(float), sums.size(), f) == sums.size();
+    fclose(f);
+    if (!ok) die("accumulator file " + path + " is not from this render (scene, size, -S, -r, --seed must match)");
+    return h.samples;
+}
+void save_accum(const std::string &path, AccumHeader h, int samples, const std::vector<float> &sums)
+{
+    h.samples = samples;
+    const std::string tmp = path + ".tmp"; // written aside and renamed: an interrupted save leaves the old file whole
+    FILE *f = fopen(tmp.c_str(), "wb");
+    bool ok = f && fwrite(&h, sizeof h, 1, f) == 1 && fwrite(sums.data(), sizeof(float), sums.size(), f) == sums.size();
+    ok = (f ? fclose(f) == 0 : false) && ok;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) die("cannot write " + path);
+}
+
 } // namespace
 
 int main(int argc, char **argv)
@@ -287,6 +335,21 @@ int main(int argc, char **argv)
     }
     if (nx <= 0 || ny <= 0 || ns <= 0 || nss <= 0) die("width, height, samples and sub-samples must be positive");
 
+    const size_t npix = (size_t)nx * ny;
+    std::vector<uint32_t> image(npix);
+    std::vector<float> accum(4 * npix);
+    const std::string accum_file = opt_str("accum");
+    const int save_every = opt_int("save-every");
+    const AccumHeader acc_head = accum_header(nx, ny, 0, nss, bounces, (uint32_t)opt_int("seed"), opt_str("scene"));
+    int samples_done = 0;
+    if (!accum_file.empty()) {
+        samples_done = load_accum(accum_file, acc_head, accum);
+        if (samples_done > 0) printf("Resuming at sample %d of %d from %s\n", samples_done, ns, accum_file.c_str());
+        if (separate) die("--accum and -m do not go together");
+    } else if (save_every) {
+        die("--save-every needs --accum");
+    }
+
     // scene and camera setup, src/main.cpp:499-511
     rt_host_scene *host = nullptr;
     check(rt_host_scene_build(opt_str("scene").c_str(), float(nx) / float(ny), &host), "scene");
@@ -296,10 +359,6 @@ int main(int argc, char **argv)
     int path_id = path == "auto" ? RT_PATH_AUTO : path == "exact" ? RT_PATH_EXACT : path == "fast" ? RT_PATH_FAST : -1;
     if (path_id < 0) die("--path takes auto, exact or fast");
     check(rt_scene_set_option(scene, RT_OPT_RENDER_PATH, path_id), "--path");
-
-    const size_t npix = (size_t)nx * ny;
-    std::vector<uint32_t> image(npix);
-    std::vector<float> accum(4 * npix);
 
     auto time_start = std::chrono::high_resolution_clock::now();
 
@@ -350,6 +409,29 @@ int main(int argc, char **argv)
         for (size_t k = 0; k < npix; ++k) {
             float c[3] = {accum[4 * k + 3] * one_over_n_samples, accum[4 * k + 2] * one_over_n_samples,
                           accum[4 * k + 1] * one_over_n_samples};
+            for (float &x : c) {
+                x = sqrtf(x);
+                x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+            }
+            image[k] = pack(c[0], c[1], c[2]);
+        }
+    } else if (!accum_file.empty()) {
+        // progressive: sample ranges [done, done + step), sums added on the host, file saved after each range
+        std::vector<float> part(4 * npix);
+        if (samples_done == 0) std::fill(accum.begin(), accum.end(), 0.0f);
+        while (samples_done < ns) {
+            const int step = save_every > 0 ? std::min(save_every, ns - samples_done) : ns - samples_done;
+            rp.sample_begin = samples_done, rp.sample_end = samples_done + step;
+            check(rt_render_to_host(scene, &rp, part.data(), nullptr), "rt_render");
+            for (size_t k = 0; k < 4 * npix; ++k) accum[k] += part[k];
+            samples_done += step;
+            save_accum(accum_file, acc_head, samples_done, accum);
+            printf("%d/%d : %.2f%%\r", samples_done, ns, 100.0f * (float)samples_done / (float)ns);
+            fflush(stdout);
+        }
+        for (size_t k = 0; k < npix; ++k) { // src/main.cpp:709-742 with the number of samples in the sums
+            const float inv = 1.0f / accum[4 * k];
+            float c[3] = {accum[4 * k + 3] * inv, accum[4 * k + 2] * inv, accum[4 * k + 1] * inv};
             for (float &x : c) {
                 x = sqrtf(x);
                 x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);

@@ -68,6 +68,56 @@ def test_no_device_is_a_loud_failure(tmp_path):
     assert not (tmp_path / "o.png").exists()
 
 
+def _accum_file(path, nx, ny, samples, nss=1, depth=50, seed=1, scene=b"cornell_box"):
+    with open(path, "wb") as f:
+        f.write(b"RTACC1\0\0" + struct.pack("<5iI", nx, ny, samples, nss, depth, seed) + scene.ljust(40, b"\0"))
+        f.write(np.zeros((ny, nx, 4), np.float32).tobytes())
+
+
+def test_accumulator_file_of_another_render_is_refused(tmp_path):
+    """--accum: the file must come from the same scene, size, -S, -r and --seed (checked before any device work)."""
+    f = str(tmp_path / "a.rtacc")
+    _accum_file(f, 8, 8, 2)
+    for args in (["-w", "16", "-h", "8"], ["-w", "8", "-h", "8", "-r", "7"], ["-w", "8", "-h", "8", "--seed", "2"],
+                 ["-w", "8", "-h", "8", "-S", "2"], ["-w", "8", "-h", "8", "--scene", "random_spheres"]):
+        p = run(args + ["-s", "4", "--accum", f] + ([] if "-r" in args else ["-r", "50"]))
+        assert p.returncode != 0 and "is not from this render" in p.stderr, args
+    open(f, "wb").write(b"RTACC1\0\0 short")
+    assert "is not from this render" in run(["-w", "8", "-h", "8", "-s", "4", "-r", "50", "--accum", f]).stderr
+    assert "--save-every needs --accum" in run(["-w", "8", "-h", "8", "--save-every", "2"]).stderr
+    assert "do not go together" in run(["-w", "8", "-h", "8", "-r", "50", "-m", "--accum", str(tmp_path / "none")]).stderr
+
+
+@pytest.mark.gpu
+def test_progressive_render_save_and_resume(tmp_path):
+    """Rendering 12 samples in one go, in saved steps of 4, or as 5 samples now and the rest after a restart gives the same
+    sums: the paths are keyed by (pixel, sample), so only float summation order can differ."""
+    nx, ny, ns = 48, 32, 12
+    common = ["-w", str(nx), "-h", str(ny), "-r", "20", "--seed", "4"]
+
+    def sums(path):
+        raw = open(path, "rb").read()
+        head = struct.unpack("<5iI", raw[8:32])
+        return head, np.frombuffer(raw[72:], np.float32).reshape(ny, nx, 4)
+
+    a, b, c = (str(tmp_path / n) for n in ("a.rtacc", "b.rtacc", "c.rtacc"))
+    assert run(common + ["-s", str(ns), "--accum", a, "-o", str(tmp_path / "a.png")]).returncode == 0
+    assert run(common + ["-s", str(ns), "--accum", b, "--save-every", "4", "-o", str(tmp_path / "b.png")]).returncode == 0
+    assert run(common + ["-s", "5", "--accum", c, "-o", str(tmp_path / "c5.png")]).returncode == 0
+    assert sums(c)[0][2] == 5
+    p = run(common + ["-s", str(ns), "--accum", c, "-o", str(tmp_path / "c.png")])
+    assert p.returncode == 0 and "Resuming at sample 5 of 12" in p.stdout
+    (ha, sa), (hb, sb), (hc, sc_) = sums(a), sums(b), sums(c)
+    assert ha == hb == hc == (nx, ny, ns, 1, 20, 4)
+    assert np.all(sa[..., 0] == ns) and np.all(sb[..., 0] == ns) and np.all(sc_[..., 0] == ns)
+    assert np.allclose(sa, sb, rtol=1e-4, atol=1e-5) and np.allclose(sa, sc_, rtol=1e-4, atol=1e-5)
+    pa, pb, pc = (read_png(str(tmp_path / n)).view(np.uint8).astype(int) for n in ("a.png", "b.png", "c.png"))
+    assert np.abs(pa - pb).max() <= 1 and np.abs(pa - pc).max() <= 1
+    # a finished file renders nothing more
+    p = run(common + ["-s", str(ns), "--accum", c, "-o", str(tmp_path / "c2.png")])
+    assert p.returncode == 0 and np.array_equal(read_png(str(tmp_path / "c2.png")), read_png(str(tmp_path / "c.png")))
+
+
 @pytest.mark.gpu
 def test_png_pixels_equal_rt_resolve(tmp_path):
     from ray_tracing_amd import api
