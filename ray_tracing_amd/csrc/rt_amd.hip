@@ -312,6 +312,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
         float t;
         int rec;
         rtf::scan<FLAT>(recs, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
+#ifdef RT_MEASURE_SCAN_TWICE // development (tools/build_variant.sh): the same scan again, to price the scan by difference
+        {
+            float t2;
+            int rec2;
+            rtf::scan<FLAT>(recs, Y, r, 0.0010001f, RT_FLT_MAX, alive, t2, rec2);
+            if (t2 < t) t = t2, rec = rec2;
+        }
+#endif
         rtf::Surface sf;
         rtf::build_surface(R, Y, r, t, rec, sf); // every lane takes part in the cross-lane fetches
 
