@@ -315,10 +315,14 @@ struct LightPick {
     uint32_t kind;
     float f0, f1, f2, f3, f4;
 };
-RTF_DEV LightPick lights_pick(const uint32_t *__restrict__ recs, const Layout &Y, Rng &rng)
+RTF_DEV int lights_index(const Layout &Y, Rng &rng)
 {
     int index = (int)(rng.next() * (float)Y.n_lights);
     if (index == Y.n_lights) index--;
+    return index;
+}
+RTF_DEV LightPick light_of_index(const uint32_t *__restrict__ recs, const Layout &Y, int index)
+{
     LightPick p{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int k = 0; k < Y.n_lights; ++k) {
         const SRec c = load_rec(recs, Y.lights_base + k);
@@ -329,16 +333,107 @@ RTF_DEV LightPick lights_pick(const uint32_t *__restrict__ recs, const Layout &Y
     }
     return p;
 }
+RTF_DEV LightPick lights_pick(const uint32_t *__restrict__ recs, const Layout &Y, Rng &rng)
+{
+    return light_of_index(recs, Y, lights_index(Y, rng));
+}
+
+// lambertian::scatter + the mixture pdf of color() (src/material.h:35-50, src/main.cpp:104-121), after the coin
+// (`to_light`) and, for a lane that samples the important list, the member (`lp`) have been drawn.
+// mixture_pdf::generate (src/pdf.h:71-79): half the lanes sample the important list, half the cosine lobe.  A sphere
+// light (sphere::random + random_to_sphere, src/sphere.h:85-103) and the cosine lobe (cosine_pdf::generate,
+// random_cosine_direction with its factor 2, src/vec3.h:179-180) are the same computation around different axes -- an
+// orthonormal basis, two draws, a point on a cap -- so those lanes run it together; a rect light (xz_rect::random,
+// src/plane.h:94-98, z takes the first draw) needs no basis.
+RTF_DEV void scatter_lambert(const uint32_t *__restrict__ recs, const Layout &Y, const Surface &h, V3 albedo, bool to_light,
+                             const LightPick &lp, Rng &rng, V3 &nd, V3 &mul, bool &go)
+{
+    const V3 wn = funit(h.n);
+    V3 dir = v3(1, 0, 0); // hitable::random, src/hitable.h:20
+    if (to_light & (lp.kind == RT_REC_LIGHT_RECT)) {
+        const float rz = rng.next(), rx = rng.next();
+        dir = v3(fmaf(rx, lp.f1 - lp.f0, lp.f0) - h.p.x, lp.f4 - h.p.y, fmaf(rz, lp.f3 - lp.f2, lp.f2) - h.p.z);
+    }
+    const bool sphere_light = to_light & (lp.kind == RT_REC_LIGHT_SPHERE);
+    if (!to_light | sphere_light) {
+        const V3 axis = sphere_light ? v3(lp.f0 - h.p.x, lp.f1 - h.p.y, lp.f2 - h.p.z) : wn;
+        Onb uvw;
+        uvw.build_from_w(axis);
+        const float r1 = rng.next();
+        const float r2 = rng.next();
+        float s, c;
+        sincos_2pi(r1, s, c);
+        float z, q;
+        if (sphere_light) {
+            z = fmaf(r2, fsqrt(1.0f - lp.f3 * lp.f3 * rcp(fdot(axis, axis))) - 1.0f, 1.0f);
+            q = fsqrt(1.0f - z * z);
+        } else {
+            z = fsqrt(1.0f - r2);
+            q = 2.0f * fsqrt(r2);
+        }
+        dir = uvw.local(v3(c * q, s * q, z));
+    }
+    dir = funit(dir);
+    const float cosine = fdot(dir, wn);
+    const float cos_val = cosine > 0.0f ? cosine * (1.0f / RT_PI) : 0.0f;
+    const float pdf_val = 0.5f * lights_pdf_value(recs, Y, h.p, dir) + 0.5f * cos_val;
+    const float sc = fmaxf(fdot(h.n, dir), 0.0f) * (1.0f / RT_PI);
+    const float wgt = sc * rcp(pdf_val);
+    nd = dir;
+    mul = v3(albedo.x * wgt, albedo.y * wgt, albedo.z * wgt);
+    go = wgt == wgt; // 0/0 is the NaN the reference's de_nan zeroes
+}
+
+// metal / dielectric / isotropic ::scatter (src/material.h:65-78, 92-145, 187-196); `mul` comes in as the albedo
+RTF_DEV void scatter_specular(const Surface &h, V3 rd, Rng &rng, V3 &nd, V3 &mul, float &ntime)
+{
+    if (h.mat_kind == RT_MAT_METAL) {
+        const V3 ud = funit(rd);
+        const float k = 2.0f * fdot(ud, h.n);
+        const V3 fz = rnd_unit_sphere(rng);
+        nd = v3(fmaf(h.p0, fz.x, ud.x - k * h.n.x), fmaf(h.p0, fz.y, ud.y - k * h.n.y), fmaf(h.p0, fz.z, ud.z - k * h.n.z));
+    } else if (h.mat_kind == RT_MAT_DIELECTRIC) {
+        const float inv_len = rsq(fdot(rd, rd));
+        const V3 ud = v3(rd.x * inv_len, rd.y * inv_len, rd.z * inv_len);
+        const float dn = fdot(rd, h.n);
+        const bool inside = dn > 0.0f;
+        const float ref_idx = h.p0;
+        const float ni_over_nt = inside ? ref_idx : rcp(ref_idx);
+        const V3 on = inside ? v3(-h.n.x, -h.n.y, -h.n.z) : h.n;
+        const float cosine = (inside ? ref_idx * dn : -dn) * inv_len;
+        const float dt = fdot(ud, on);
+        const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+        float reflect_prob = 1.0f;
+        if (disc > 0.0f) { // schlick, src/utils.h:4-9
+            float r0 = (1.0f - ref_idx) * rcp(1.0f + ref_idx);
+            r0 = r0 * r0;
+            const float x = 1.0f - cosine, x2 = x * x;
+            reflect_prob = fmaf(1.0f - r0, x2 * x2 * x, r0);
+        }
+        // reflect (src/utils.h:11-14) and refract (src/utils.h:16-30) as one expression a*ud + b*n:
+        const bool reflect = rng.next() < reflect_prob;
+        const float k = 2.0f * fdot(ud, h.n);
+        const float sq = fsqrt(fmaxf(disc, 0.0f));
+        const float ca = reflect ? 1.0f : ni_over_nt;
+        const float cb = reflect ? -k : -(ni_over_nt * dt + sq);
+        const V3 nn = reflect ? h.n : on;
+        nd = v3(fmaf(ca, ud.x, cb * nn.x), fmaf(ca, ud.y, cb * nn.y), fmaf(ca, ud.z, cb * nn.z));
+        mul = v3(1, 1, 1); // attenuation (1,1,1), src/material.h:100
+    } else { // isotropic
+        nd = rnd_unit_sphere(rng);
+        ntime = 0.0f;
+    }
+}
 
 // One bounce of color() (src/main.cpp:91-127) in throughput form; see rt::shade for the derivation.
-// TEX: the scene has a non-constant texture (noise / checker); those are evaluated from the memory tables.
+// TEX: the scene has a non-constant texture (noise / checker / image); those are evaluated from the memory tables.
+// Every branch only PRODUCES (next direction, throughput factor); ray and throughput are written once, after the
+// branches have joined.  (Writing them inside the divergent branches makes the compiler shuttle the whole path state
+// through copies at every join.)
 template <bool TEX>
 RTF_DEV bool shade(const DevScene &S, const uint32_t *__restrict__ recs, const Layout &Y, bool hit_any, const Surface &h, Ray &r, V3 &T,
                    int &depth, int max_depth, Rng &rng, V3 &L)
 {
-    // Every branch below only PRODUCES (next direction, throughput factor); ray and throughput are written once, after
-    // the branches have joined.  (Writing them inside the divergent branches makes the compiler shuttle the whole path
-    // state through copies at every join.)
     L = v3(0, 0, 0);
     bool go = false;
     V3 nd = r.d, mul = v3(1, 1, 1);
@@ -352,83 +447,12 @@ RTF_DEV bool shade(const DevScene &S, const uint32_t *__restrict__ recs, const L
             go = true;
             mul = albedo;
             if (h.mat_kind == RT_MAT_LAMBERTIAN) {
-                // mixture_pdf::generate (src/pdf.h:71-79): half the lanes sample the important list, half the cosine lobe.
-                // A sphere light (sphere::random + random_to_sphere, src/sphere.h:85-103) and the cosine lobe
-                // (cosine_pdf::generate, random_cosine_direction with its factor 2, src/vec3.h:179-180) are the same
-                // computation around different axes -- an orthonormal basis, two draws, a point on a cap -- so those lanes
-                // run it together; a rect light (xz_rect::random, src/plane.h:94-98, z takes the first draw) needs no basis.
-                const V3 wn = funit(h.n);
                 const bool to_light = rng.next() < 0.5f;
                 LightPick lp{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 if (to_light) lp = lights_pick(recs, Y, rng);
-                V3 dir = v3(1, 0, 0); // hitable::random, src/hitable.h:20
-                if (to_light & (lp.kind == RT_REC_LIGHT_RECT)) {
-                    const float rz = rng.next(), rx = rng.next();
-                    dir = v3(fmaf(rx, lp.f1 - lp.f0, lp.f0) - h.p.x, lp.f4 - h.p.y, fmaf(rz, lp.f3 - lp.f2, lp.f2) - h.p.z);
-                }
-                const bool sphere_light = to_light & (lp.kind == RT_REC_LIGHT_SPHERE);
-                if (!to_light | sphere_light) {
-                    const V3 axis = sphere_light ? v3(lp.f0 - h.p.x, lp.f1 - h.p.y, lp.f2 - h.p.z) : wn;
-                    Onb uvw;
-                    uvw.build_from_w(axis);
-                    const float r1 = rng.next();
-                    const float r2 = rng.next();
-                    float s, c;
-                    sincos_2pi(r1, s, c);
-                    float z, q;
-                    if (sphere_light) {
-                        z = fmaf(r2, fsqrt(1.0f - lp.f3 * lp.f3 * rcp(fdot(axis, axis))) - 1.0f, 1.0f);
-                        q = fsqrt(1.0f - z * z);
-                    } else {
-                        z = fsqrt(1.0f - r2);
-                        q = 2.0f * fsqrt(r2);
-                    }
-                    dir = uvw.local(v3(c * q, s * q, z));
-                }
-                dir = funit(dir);
-                const float cosine = fdot(dir, wn);
-                const float cos_val = cosine > 0.0f ? cosine * (1.0f / RT_PI) : 0.0f;
-                const float pdf_val = 0.5f * lights_pdf_value(recs, Y, h.p, dir) + 0.5f * cos_val;
-                const float sc = fmaxf(fdot(h.n, dir), 0.0f) * (1.0f / RT_PI);
-                const float wgt = sc * rcp(pdf_val);
-                nd = dir;
-                mul = v3(albedo.x * wgt, albedo.y * wgt, albedo.z * wgt);
-                go = wgt == wgt; // 0/0 is the NaN the reference's de_nan zeroes
-            } else if (h.mat_kind == RT_MAT_METAL) { // src/material.h:65-78
-                const V3 ud = funit(r.d);
-                const float k = 2.0f * fdot(ud, h.n);
-                const V3 fz = rnd_unit_sphere(rng);
-                nd = v3(fmaf(h.p0, fz.x, ud.x - k * h.n.x), fmaf(h.p0, fz.y, ud.y - k * h.n.y), fmaf(h.p0, fz.z, ud.z - k * h.n.z));
-            } else if (h.mat_kind == RT_MAT_DIELECTRIC) { // src/material.h:92-145
-                const float inv_len = rsq(fdot(r.d, r.d));
-                const V3 ud = v3(r.d.x * inv_len, r.d.y * inv_len, r.d.z * inv_len);
-                const float dn = fdot(r.d, h.n);
-                const bool inside = dn > 0.0f;
-                const float ref_idx = h.p0;
-                const float ni_over_nt = inside ? ref_idx : rcp(ref_idx);
-                const V3 on = inside ? v3(-h.n.x, -h.n.y, -h.n.z) : h.n;
-                const float cosine = (inside ? ref_idx * dn : -dn) * inv_len;
-                const float dt = fdot(ud, on);
-                const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
-                float reflect_prob = 1.0f;
-                if (disc > 0.0f) { // schlick, src/utils.h:4-9
-                    float r0 = (1.0f - ref_idx) * rcp(1.0f + ref_idx);
-                    r0 = r0 * r0;
-                    const float x = 1.0f - cosine, x2 = x * x;
-                    reflect_prob = fmaf(1.0f - r0, x2 * x2 * x, r0);
-                }
-                // reflect (src/utils.h:11-14) and refract (src/utils.h:16-30) as one expression a*ud + b*n:
-                const bool reflect = rng.next() < reflect_prob;
-                const float k = 2.0f * fdot(ud, h.n);
-                const float sq = fsqrt(fmaxf(disc, 0.0f));
-                const float ca = reflect ? 1.0f : ni_over_nt;
-                const float cb = reflect ? -k : -(ni_over_nt * dt + sq);
-                const V3 nn = reflect ? h.n : on;
-                nd = v3(fmaf(ca, ud.x, cb * nn.x), fmaf(ca, ud.y, cb * nn.y), fmaf(ca, ud.z, cb * nn.z));
-                mul = v3(1, 1, 1); // attenuation (1,1,1), src/material.h:100
-            } else { // isotropic, src/material.h:187-196
-                nd = rnd_unit_sphere(rng);
-                ntime = 0.0f;
+                scatter_lambert(recs, Y, h, albedo, to_light, lp, rng, nd, mul, go);
+            } else {
+                scatter_specular(h, r.d, rng, nd, mul, ntime);
             }
             ++depth;
         }
