@@ -236,16 +236,22 @@ int rt_trace_rays(rt_scene* scene, int32_t n, const float* h_rays, float t_min, 
 /* ------------------------------------------------------------------ */
 /* Execution paths                                                      */
 /* ------------------------------------------------------------------ */
-/* The library holds two device implementations of world->hit() + color():
- *   RT_PATH_EXACT  scene tables in memory, read through wave-uniform scalar loads;
- *                  any scene the flattener accepts; every float operation that
- *                  decides a hit repeats the reference's, so ids, t, p and normal
- *                  equal the CPU reference bit for bit.
- *   RT_PATH_FAST   scenes of at most 64 records (the Cornell box: 33) held in
- *                  registers, hardware-rate reciprocal/sqrt and FMA; same algorithm,
- *                  same random-draw order, results equal up to rounding.
- * RT_PATH_AUTO (default): rt_render uses FAST when the scene fits, else EXACT;
- * rt_trace_rays uses EXACT.  No counterpart in the reference (it has one CPU path). */
+/* The library holds an exact and a fast device implementation of world->hit() + color():
+ *   RT_PATH_EXACT  scene tables in memory; any scene the flattener accepts; every float operation that
+ *                  decides a hit repeats the reference's, so ids, t, p and normal equal the CPU
+ *                  reference bit for bit (the reference's own tree, walked wave-uniformly when it has at
+ *                  most 64 entries, else per lane, ordered and culled without changing the result).
+ *   RT_PATH_FAST   hardware-rate reciprocal/sqrt and FMA; same algorithm, same random-draw order per
+ *                  primitive, results equal up to rounding (and up to which of two hits at exactly the
+ *                  same distance wins).  Two forms, chosen by the scene:
+ *                  - at most 64 records (the Cornell box: 23), static spheres / rects / boxes: the scene
+ *                    lives in registers and is scanned wave-uniformly (RT_INFO_RECORDS > 0);
+ *                  - anything else (media, moving spheres, (u,v) textures, up to millions of primitives):
+ *                    every lane walks the library's own surface-area-heuristic tree over the same
+ *                    primitives (RT_INFO_RECORDS == -1).
+ * RT_PATH_AUTO (default): rt_render uses FAST, except for scenes of at most 64 tree entries that do not
+ * fit the record table (their wave-uniform exact walk is the faster one); rt_trace_rays uses EXACT.
+ * No counterpart in the reference (it has one CPU path). */
 enum rt_option { RT_OPT_RENDER_PATH = 1, RT_OPT_TRACE_PATH = 2 };
 enum rt_path { RT_PATH_AUTO = 0, RT_PATH_EXACT = 1, RT_PATH_FAST = 2 };
 int rt_scene_set_option(rt_scene* scene, int option, int value);
