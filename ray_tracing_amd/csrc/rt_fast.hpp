@@ -138,10 +138,85 @@ RTF_DEV bool rect_in(const SRec &c, float ok, float ik, float oa, float da, floa
     return (t >= t_min) & (t <= bound) & (a >= sf(c, 0)) & (a <= sf(c, 1)) & (b >= sf(c, 2)) & (b <= sf(c, 3));
 }
 
+// One rect record against the ray of its chain, and the update of the lane's best hit, as ONE block of machine code.
+// What the compiler makes of rect_in() is 6 v_cmp + 5 s_and_b64 + 2 v_cndmask; the SIMD issues one scalar instruction
+// per turn just like one vector instruction, and with the loop's own scalar work the scan was bound by the scalar pipe
+// (35 scalar against 13 vector instructions per record).  Here the six comparisons narrow EXEC one after the other
+// (v_cmpx), the two moves run under what is left, and EXEC is restored: 12 vector and 2 scalar instructions.
+// Comparisons in positive form, so a NaN is never a hit.
+RTF_DEV void rect_update(float k, float a0, float a1, float b0, float b1, float t_min, int index, float ok, float ik, float oa,
+                         float da, float ob, float db, float &best_t, int &best_rec)
+{
+    float t, a, b;
+    unsigned long long saved;
+    asm volatile("v_sub_f32 %[t], %[k], %[ok]\n\t"
+                 "v_mul_f32 %[t], %[t], %[ik]\n\t"
+                 "v_fma_f32 %[a], %[t], %[da], %[oa]\n\t"
+                 "v_fma_f32 %[b], %[t], %[db], %[ob]\n\t"
+                 "s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_le_f32 %[tmin], %[t]\n\t"
+                 "v_cmpx_ge_f32 %[bt], %[t]\n\t"
+                 "v_cmpx_le_f32 %[a0], %[a]\n\t"
+                 "v_cmpx_ge_f32 %[a1], %[a]\n\t"
+                 "v_cmpx_le_f32 %[b0], %[b]\n\t"
+                 "v_cmpx_ge_f32 %[b1], %[b]\n\t"
+                 "v_mov_b32 %[bt], %[t]\n\t"
+                 "v_mov_b32 %[br], %[idx]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [t] "=&v"(t), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(saved), [bt] "+v"(best_t), [br] "+v"(best_rec)
+                 : [k] "s"(k), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1), [tmin] "s"(t_min), [idx] "s"(index),
+                   [ok] "v"(ok), [ik] "v"(ik), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob), [db] "v"(db)
+                 : "vcc");
+}
+
+// The scan of a FLAT stream (no box records; stored chain by chain, rt_records.cpp).  Dead lanes run along (their rays
+// are finite leftovers); `alive` is applied once at the end.  No software prefetch: eight waves per SIMD hide the scalar
+// load, and rotating a prefetched record through copies costs seven scalar moves per record.
+RTF_DEV void scan_flat(const uint32_t *__restrict__ recs, const Layout &Y, const Ray &wr, float t_min, float t_max, bool alive,
+                       float &best_t, int &best_rec)
+{
+    best_t = t_max;
+    best_rec = -1;
+    LocalRay l;
+    set_local(l, wr.o, wr.d);
+    const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
+    for (int i = 0; i < Y.n_stream; ++i) {
+        const SRec c = load_rec(recs, i);
+        const uint32_t kw = c.d[7];
+        if (kw & RT_KW_ENTER) apply_chain(recs, (kw >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK, wr, l);
+        const uint32_t kind_axis = kw & 0x3fu; // kind | axis << 4
+        if (kind_axis == (RT_REC_RECT | (0u << RT_KW_AXIS_SHIFT))) {
+            rect_update(sf(c, 4), sf(c, 0), sf(c, 1), sf(c, 2), sf(c, 3), t_min, i, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, best_t, best_rec);
+        } else if (kind_axis == (RT_REC_RECT | (1u << RT_KW_AXIS_SHIFT))) {
+            rect_update(sf(c, 4), sf(c, 0), sf(c, 1), sf(c, 2), sf(c, 3), t_min, i, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, best_t, best_rec);
+        } else if (kind_axis == (RT_REC_RECT | (2u << RT_KW_AXIS_SHIFT))) {
+            rect_update(sf(c, 4), sf(c, 0), sf(c, 1), sf(c, 2), sf(c, 3), t_min, i, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best_t, best_rec);
+        } else { // sphere, world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree
+            const V3 oc = v3(wr.o.x - sf(c, 0), wr.o.y - sf(c, 1), wr.o.z - sf(c, 2));
+            const float radius = sf(c, 3);
+            const float b = fdot(oc, wr.d);
+            const float cc = fmaf(-radius, radius, fdot(oc, oc));
+            const float disc = fmaf(b, b, -(w_dd * cc));
+            const float sq = fsqrt(disc);
+            const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
+            const bool in1 = (t1 < t_max) & (t1 > t_min), in2 = (t2 < t_max) & (t2 > t_min);
+            const float t = in1 ? t1 : t2;
+            const bool in = (disc > 0.0f) & (in1 | in2) & (t <= best_t);
+            best_t = in ? t : best_t;
+            best_rec = in ? i : best_rec;
+        }
+    }
+    best_rec = alive ? best_rec : -1;
+}
+
 template <bool FLAT>
 RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray &wr, float t_min, float t_max,
                   bool alive, float &best_t, int &best_rec)
 {
+    if (FLAT) {
+        scan_flat(recs, Y, wr, t_min, t_max, alive, best_t, best_rec);
+        return;
+    }
     best_t = t_max;
     best_rec = -1;
     int resume = 0;

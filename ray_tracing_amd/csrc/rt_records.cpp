@@ -1,6 +1,7 @@
 // rt_records.cpp -- builds the register-resident record table (rt_records.h) from a scene description.
 #include "rt_records.h"
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -224,6 +225,26 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
         } else {
             emit_prim(s, en.a, p, p.chain, RT_KW_FIRST | RT_KW_LAST);
         }
+    }
+    // A flat stream is stored chain by chain, world-space records first; the first record of a run under an instance
+    // chain carries RT_KW_ENTER.  The scan (rt_fast.hpp, scan_flat) then transforms the ray once per chain, never back,
+    // and decides it with one bit test.  The order of a flat stream only decides which of two hits at the SAME distance
+    // is kept.
+    if (out->flat) {
+        std::vector<int> order(n_stream);
+        for (int i = 0; i < n_stream; ++i) order[i] = i;
+        auto key = [&](const uint32_t *r) {
+            return (r[7] & 15u) == RT_REC_SPHERE ? 0u : (r[7] >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK;
+        };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(out->rec[a]) < key(out->rec[b]); });
+        rt_record_table tmp = *out;
+        for (int i = 0; i < n_stream; ++i) {
+            memcpy(out->rec[i], tmp.rec[order[i]], sizeof out->rec[i]);
+            out->user_id[i] = tmp.user_id[order[i]];
+            out->prim[i] = tmp.prim[order[i]];
+        }
+        for (int i = 0; i < n_stream; ++i)
+            if (key(out->rec[i]) != 0u && (i == 0 || key(out->rec[i - 1]) != key(out->rec[i]))) out->rec[i][7] |= RT_KW_ENTER;
     }
     return 1;
 }

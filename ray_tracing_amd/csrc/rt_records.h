@@ -49,6 +49,7 @@ enum rt_rec_kind {
 #define RT_KW_CHAIN_MASK 0x1ffu
 #define RT_KW_MAT_SHIFT 18
 #define RT_KW_MAT_MASK 0xffu
+#define RT_KW_ENTER (1u << 26) /* flat streams (stored chain by chain): first record of a run under an instance chain */
 
 typedef struct rt_record_table {
     uint32_t rec[RT_REC_MAX + 1][8]; /* one spare record: the scan prefetches record i+1 */
