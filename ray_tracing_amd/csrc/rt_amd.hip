@@ -253,6 +253,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
                                                                             rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
 {
     __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
+    __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8]; // the record table, for the broadcast reads of the flat scan
+    for (int k = threadIdx.x; k < (RT_REC_MAX + 1) * 8; k += 64 * WAVES_PER_BLOCK) lrecs[k] = recs[k];
+    __syncthreads(); // before any wave leaves
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -311,12 +314,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
 
         float t;
         int rec;
-        rtf::scan<FLAT>(recs, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
+        rtf::scan<FLAT>(recs, lrecs, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
 #ifdef RT_MEASURE_SCAN_TWICE // development (tools/build_variant.sh): the same scan again, to price the scan by difference
         {
             float t2;
             int rec2;
-            rtf::scan<FLAT>(recs, Y, r, 0.0010001f, RT_FLT_MAX, alive, t2, rec2);
+            rtf::scan<FLAT>(recs, lrecs, Y, r, 0.0010001f, RT_FLT_MAX, alive, t2, rec2);
             if (t2 < t) t = t2, rec = rec2;
         }
 #endif
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
     float t;
     int rec;
-    rtf::scan<false>(recs, Y, r, t_min, t_max, alive, t, rec); // the general form also walks flat streams
+    rtf::scan<false>(recs, nullptr, Y, r, t_min, t_max, alive, t, rec); // the general form also walks flat streams
     rtf::Surface sf;
     rtf::build_surface(R, Y, r, t, rec, sf);
     const uint32_t kw = rtf::sh_u(R.d[7], rec < 0 ? 0 : rec);
@@ -523,7 +526,7 @@ struct rt_scene {
     bool fast_flat = false;     // the record stream holds no box records
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     const char *fast_why = "";
-    rtf::Layout layout{0, 0, 0, 0};
+    rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids (inside blob)
     int32_t *d_rec_user = nullptr;
     int render_path = RT_PATH_AUTO, trace_path = RT_PATH_AUTO;
@@ -720,7 +723,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         s->fast_textured |= d->materials[m].texture >= 0 && d->textures[d->materials[m].texture].kind != RT_TEX_CONSTANT;
     s->d_records = (uint32_t *)(b + parts[8].off);
     s->d_rec_user = (int32_t *)(b + parts[9].off);
-    s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights};
+    s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights, {tab.run[0], tab.run[1], tab.run[2], tab.run[3]}, tab.n_runs, tab.n_spheres};
     s->fast_flat = fast_ok && tab.flat != 0;
     *out = s;
     return RT_OK;

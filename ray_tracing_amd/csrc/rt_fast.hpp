@@ -72,6 +72,8 @@ RTF_DEV float sh_f(uint32_t v, int lane) { return __uint_as_float(sh_u(v, lane))
 
 struct Layout { // wave-uniform description of the table
     int32_t n_stream, materials_base, lights_base, n_lights;
+    uint32_t run[RT_REC_MAX_RUNS]; // rt_records.h: the runs of a flat stream
+    int32_t n_runs, n_spheres;
 };
 
 // the ray in the space of the current chain, with what the slab and rect tests need
@@ -144,29 +146,95 @@ RTF_DEV bool rect_in(const SRec &c, float ok, float ik, float oa, float da, floa
 // (35 scalar against 13 vector instructions per record).  Here the six comparisons narrow EXEC one after the other
 // (v_cmpx), the two moves run under what is left, and EXEC is restored: 12 vector and 2 scalar instructions.
 // Comparisons in positive form, so a NaN is never a hit.
-RTF_DEV void rect_update(float k, float a0, float a1, float b0, float b1, float t_min, int index, float ok, float ik, float oa,
-                         float da, float ob, float db, float &best_t, int &best_rec)
+#define RTF_RECT_UPDATE(NAME, RC)                                                                                        \
+    RTF_DEV void NAME(float k, float a0, float a1, float b0, float b1, float t_min, int index, float ok, float ik, float oa, \
+                      float da, float ob, float db, float &best_t, int &best_rec)                                         \
+    {                                                                                                                    \
+        float t, a, b;                                                                                                   \
+        unsigned long long saved;                                                                                        \
+        asm volatile("v_sub_f32 %[t], %[k], %[ok]\n\t"                                                                   \
+                     "v_mul_f32 %[t], %[t], %[ik]\n\t"                                                                   \
+                     "v_fma_f32 %[a], %[t], %[da], %[oa]\n\t"                                                            \
+                     "v_fma_f32 %[b], %[t], %[db], %[ob]\n\t"                                                            \
+                     "s_mov_b64 %[sv], exec\n\t"                                                                         \
+                     "v_cmpx_le_f32 %[tmin], %[t]\n\t"                                                                   \
+                     "v_cmpx_ge_f32 %[bt], %[t]\n\t"                                                                     \
+                     "v_cmpx_le_f32 %[a0], %[a]\n\t"                                                                     \
+                     "v_cmpx_ge_f32 %[a1], %[a]\n\t"                                                                     \
+                     "v_cmpx_le_f32 %[b0], %[b]\n\t"                                                                     \
+                     "v_cmpx_ge_f32 %[b1], %[b]\n\t"                                                                     \
+                     "v_mov_b32 %[bt], %[t]\n\t"                                                                         \
+                     "v_mov_b32 %[br], %[idx]\n\t"                                                                       \
+                     "s_mov_b64 exec, %[sv]"                                                                             \
+                     : [t] "=&v"(t), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(saved), [bt] "+v"(best_t), [br] "+v"(best_rec) \
+                     : [k] RC(k), [a0] RC(a0), [a1] RC(a1), [b0] RC(b0), [b1] RC(b1), [tmin] "s"(t_min), [idx] "s"(index), \
+                       [ok] "v"(ok), [ik] "v"(ik), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob), [db] "v"(db)                \
+                     : "vcc");                                                                                           \
+    }
+RTF_RECT_UPDATE(rect_update, "s")   // record fields in SGPRs (scalar loads)
+RTF_RECT_UPDATE(rect_update_v, "v") // record fields in VGPRs (broadcast reads from LDS)
+
+// `count` rect records of one chain and axis from record `index` on: nothing to decode, the loop is fetch + test.
+// The records come from the block's copy of the table in LDS with broadcast reads (every lane the same address): the
+// LDS pipe is idle otherwise, the scalar pipe was the busy one, and the next record's read is in flight during the test.
+struct LRec {
+    uint4 a;   // a0 a1 b0 b1 (rect) | cx cy cz r (sphere)
+    uint32_t k; // rect: the plane
+};
+RTF_DEV LRec lds_rec(const uint32_t *lrecs, int i)
 {
-    float t, a, b;
-    unsigned long long saved;
-    asm volatile("v_sub_f32 %[t], %[k], %[ok]\n\t"
-                 "v_mul_f32 %[t], %[t], %[ik]\n\t"
-                 "v_fma_f32 %[a], %[t], %[da], %[oa]\n\t"
-                 "v_fma_f32 %[b], %[t], %[db], %[ob]\n\t"
-                 "s_mov_b64 %[sv], exec\n\t"
-                 "v_cmpx_le_f32 %[tmin], %[t]\n\t"
-                 "v_cmpx_ge_f32 %[bt], %[t]\n\t"
-                 "v_cmpx_le_f32 %[a0], %[a]\n\t"
-                 "v_cmpx_ge_f32 %[a1], %[a]\n\t"
-                 "v_cmpx_le_f32 %[b0], %[b]\n\t"
-                 "v_cmpx_ge_f32 %[b1], %[b]\n\t"
-                 "v_mov_b32 %[bt], %[t]\n\t"
-                 "v_mov_b32 %[br], %[idx]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [t] "=&v"(t), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(saved), [bt] "+v"(best_t), [br] "+v"(best_rec)
-                 : [k] "s"(k), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1), [tmin] "s"(t_min), [idx] "s"(index),
-                   [ok] "v"(ok), [ik] "v"(ik), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob), [db] "v"(db)
-                 : "vcc");
+    LRec r;
+    r.a = *reinterpret_cast<const uint4 *>(lrecs + 8 * i);
+    r.k = lrecs[8 * i + 4];
+    return r;
+}
+RTF_DEV void rect_run(const uint32_t *lrecs, int &index, int count, float t_min, float ok, float ik, float oa, float da, float ob,
+                      float db, float &best_t, int &best_rec)
+{
+    LRec nxt = lds_rec(lrecs, index);
+    for (int k = 0; k < count; ++k, ++index) {
+        const LRec c = nxt;
+        nxt = lds_rec(lrecs, index + 1); // the table is padded: one record past the stream exists
+        rect_update_v(__uint_as_float(c.k), __uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
+                    t_min, index, ok, ik, oa, da, ob, db, best_t, best_rec);
+    }
+}
+
+// The scan of a flat stream stored in runs (rt_records.h): per chain three loops of rects (one per axis), then the
+// spheres; run lengths come from the kernel arguments, so a record costs its fetch, its test and the loop's counter.
+// `lrecs`: the record stream in LDS; `recs`: the table in memory (instance chains, read with scalar loads).
+RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min,
+                       float t_max, bool alive, float &best_t, int &best_rec)
+{
+    best_t = t_max;
+    best_rec = -1;
+    LocalRay l;
+    set_local(l, wr.o, wr.d);
+    int index = 0;
+    for (int r = 0; r < Y.n_runs; ++r) {
+        const uint32_t w = Y.run[r];
+        if (w >> 15) apply_chain(recs, w >> 15, wr, l);
+        rect_run(lrecs, index, (int)((w >> 10) & 31u), t_min, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, best_t, best_rec);
+        rect_run(lrecs, index, (int)((w >> 5) & 31u), t_min, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, best_t, best_rec);
+        rect_run(lrecs, index, (int)(w & 31u), t_min, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best_t, best_rec);
+    }
+    const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
+    for (int k = 0; k < Y.n_spheres; ++k, ++index) { // world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree
+        const LRec c = lds_rec(lrecs, index);
+        const V3 oc = v3(wr.o.x - __uint_as_float(c.a.x), wr.o.y - __uint_as_float(c.a.y), wr.o.z - __uint_as_float(c.a.z));
+        const float radius = __uint_as_float(c.a.w);
+        const float b = fdot(oc, wr.d);
+        const float cc = fmaf(-radius, radius, fdot(oc, oc));
+        const float disc = fmaf(b, b, -(w_dd * cc));
+        const float sq = fsqrt(disc);
+        const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
+        const bool in1 = (t1 < t_max) & (t1 > t_min), in2 = (t2 < t_max) & (t2 > t_min);
+        const float t = in1 ? t1 : t2;
+        const bool in = (disc > 0.0f) & (in1 | in2) & (t <= best_t);
+        best_t = in ? t : best_t;
+        best_rec = in ? index : best_rec;
+    }
+    best_rec = alive ? best_rec : -1;
 }
 
 // The scan of a FLAT stream (no box records; stored chain by chain, rt_records.cpp).  Dead lanes run along (their rays
@@ -210,11 +278,12 @@ RTF_DEV void scan_flat(const uint32_t *__restrict__ recs, const Layout &Y, const
 }
 
 template <bool FLAT>
-RTF_DEV void scan(const uint32_t *__restrict__ recs, const Layout &Y, const Ray &wr, float t_min, float t_max,
+RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min, float t_max,
                   bool alive, float &best_t, int &best_rec)
 {
     if (FLAT) {
-        scan_flat(recs, Y, wr, t_min, t_max, alive, best_t, best_rec);
+        if (Y.n_runs > 0) scan_runs(recs, lrecs, Y, wr, t_min, t_max, alive, best_t, best_rec);
+        else scan_flat(recs, Y, wr, t_min, t_max, alive, best_t, best_rec);
         return;
     }
     best_t = t_max;

@@ -226,15 +226,18 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             emit_prim(s, en.a, p, p.chain, RT_KW_FIRST | RT_KW_LAST);
         }
     }
-    // A flat stream is stored chain by chain, world-space records first; the first record of a run under an instance
-    // chain carries RT_KW_ENTER.  The scan (rt_fast.hpp, scan_flat) then transforms the ray once per chain, never back,
-    // and decides it with one bit test.  The order of a flat stream only decides which of two hits at the SAME distance
-    // is kept.
+    // A flat stream is stored in runs: chain by chain (world space first), within a chain the rects by axis, and all
+    // spheres (world space) at the end.  The scan (rt_fast.hpp) then runs one tight loop per run, with nothing to decode
+    // per record; the run lengths travel in the kernel arguments.  The first record of a run under an instance chain
+    // also carries RT_KW_ENTER, for the scan that decodes record by record (more than RT_REC_MAX_RUNS chains).
+    // The order of a flat stream only decides which of two hits at the SAME distance is kept.
     if (out->flat) {
         std::vector<int> order(n_stream);
         for (int i = 0; i < n_stream; ++i) order[i] = i;
+        auto chain_of = [&](const uint32_t *r) { return (r[7] >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK; };
         auto key = [&](const uint32_t *r) {
-            return (r[7] & 15u) == RT_REC_SPHERE ? 0u : (r[7] >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK;
+            if ((r[7] & 15u) == RT_REC_SPHERE) return 0xffffffffu;
+            return (chain_of(r) << 2) | ((r[7] >> RT_KW_AXIS_SHIFT) & 3u);
         };
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(out->rec[a]) < key(out->rec[b]); });
         rt_record_table tmp = *out;
@@ -243,8 +246,28 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             out->user_id[i] = tmp.user_id[order[i]];
             out->prim[i] = tmp.prim[order[i]];
         }
-        for (int i = 0; i < n_stream; ++i)
-            if (key(out->rec[i]) != 0u && (i == 0 || key(out->rec[i - 1]) != key(out->rec[i]))) out->rec[i][7] |= RT_KW_ENTER;
+        int n_runs = 0;
+        bool fits = true;
+        uint32_t counts[RT_REC_MAX_RUNS][3] = {};
+        uint32_t chains[RT_REC_MAX_RUNS] = {};
+        for (int i = 0; i < n_stream; ++i) {
+            uint32_t *r = out->rec[i];
+            if ((r[7] & 15u) == RT_REC_SPHERE) {
+                ++out->n_spheres;
+                continue;
+            }
+            const bool first = i == 0 || chain_of(out->rec[i - 1]) != chain_of(r);
+            if (first && chain_of(r) != 0u) r[7] |= RT_KW_ENTER;
+            if (first) {
+                if (n_runs == RT_REC_MAX_RUNS) { fits = false; continue; }
+                chains[n_runs++] = chain_of(r);
+            }
+            if (fits && ++counts[n_runs - 1][(r[7] >> RT_KW_AXIS_SHIFT) & 3u] > 31u) fits = false;
+        }
+        out->n_runs = fits ? n_runs : 0;
+        if (fits && n_runs == 0 && out->n_spheres > 0) out->n_runs = 1; // spheres only: one empty run in world space
+        for (int k = 0; k < RT_REC_MAX_RUNS; ++k)
+            out->run[k] = fits ? (chains[k] << 15) | (counts[k][0] << 10) | (counts[k][1] << 5) | counts[k][2] : 0u;
     }
     return 1;
 }

@@ -60,7 +60,13 @@ typedef struct rt_record_table {
     int32_t lights_base, n_lights;
     int32_t n_records;
     int32_t flat;                /* 1: the stream holds no inner (box) records */
+    /* flat streams are stored in RUNS: for each instance chain (world space first) its rects by axis (xy, xz, yz), then
+     * all spheres (world space).  run[r] = chain word << 15 | n_xy << 10 | n_xz << 5 | n_yz.  n_runs == 0: the stream
+     * has more than RT_REC_MAX_RUNS chains and the scan decodes every record instead. */
+    uint32_t run[4];
+    int32_t n_runs, n_spheres;
 } rt_record_table;
+#define RT_REC_MAX_RUNS 4
 
 #ifdef __cplusplus
 extern "C" {
