@@ -326,6 +326,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
         rtf::Surface sf;
         rtf::build_surface(R, Y, r, t, rec, sf); // every lane takes part in the cross-lane fetches
 
+#ifdef RT_MEASURE_SHADE_TWICE // development (tools/build_variant.sh): the shade once more on a copy of the path, kept alive at zero weight
+        float keep = 0.0f;
+        if (alive) {
+            Ray r2 = r;
+            V3 T2 = T, L2;
+            int depth2 = depth;
+            Rng rng2{rng.x ^ 0x5bd1e995u};
+            const bool g2 = rtf::shade<TEX>(S, recs, Y, rec >= 0, sf, r2, T2, depth2, A.max_depth, rng2, L2);
+            keep = (g2 ? r2.d.x + T2.y : L2.z) * 1e-30f;
+        }
+#endif
         if (alive) {
             V3 L;
             if (!rtf::shade<TEX>(S, recs, Y, rec >= 0, sf, r, T, depth, A.max_depth, rng, L)) {
@@ -334,6 +345,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
                 if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
                 if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[128 + pix], L.z);
             }
+#ifdef RT_MEASURE_SHADE_TWICE
+            T.x += keep * 1e-30f;
+#endif
         }
     }
 

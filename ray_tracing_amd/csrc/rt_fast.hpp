@@ -191,10 +191,8 @@ RTF_DEV LRec lds_rec(const uint32_t *lrecs, int i)
 RTF_DEV void rect_run(const uint32_t *lrecs, int &index, int count, float t_min, float ok, float ik, float oa, float da, float ob,
                       float db, float &best_t, int &best_rec)
 {
-    LRec nxt = lds_rec(lrecs, index);
     for (int k = 0; k < count; ++k, ++index) {
-        const LRec c = nxt;
-        nxt = lds_rec(lrecs, index + 1); // the table is padded: one record past the stream exists
+        const LRec c = lds_rec(lrecs, index);
         rect_update_v(__uint_as_float(c.k), __uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
                     t_min, index, ok, ik, oa, da, ob, db, best_t, best_rec);
     }
