@@ -576,29 +576,25 @@ template <bool TEX>
 RTF_DEV bool shade(const DevScene &S, const uint32_t *__restrict__ recs, const Layout &Y, bool hit_any, const Surface &h, Ray &r, V3 &T,
                    int &depth, int max_depth, Rng &rng, V3 &L)
 {
-    L = v3(0, 0, 0);
-    bool go = false;
-    V3 nd = r.d, mul = v3(1, 1, 1);
+    // what happens to the path is settled first, with selects; then come FLAT branches, one per fate (nested
+    // branches make the compiler re-initialise every value that leaves them at every level of the nest)
+    enum { END = 0, LIGHT = 1, DIFFUSE = 2, SPECULAR = 3 };
+    const bool is_light = h.mat_kind == RT_MAT_DIFFUSE_LIGHT;
+    const int fate = !hit_any ? END : is_light ? LIGHT : !(depth < max_depth) ? END : h.mat_kind == RT_MAT_LAMBERTIAN ? DIFFUSE : SPECULAR;
+    V3 albedo = h.color;
+    if (TEX && hit_any && h.texture >= 0) albedo = rt::tex_value(S, h.texture, h.u, h.v, h.p);
+    L = fate == LIGHT ? v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z) : v3(0, 0, 0);
+    bool go = fate >= DIFFUSE;
+    V3 nd = r.d, mul = albedo;
     float ntime = r.time;
-    if (hit_any) {
-        V3 albedo = h.color;
-        if (TEX && h.texture >= 0) albedo = rt::tex_value(S, h.texture, h.u, h.v, h.p);
-        if (h.mat_kind == RT_MAT_DIFFUSE_LIGHT) {
-            L = v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
-        } else if (depth < max_depth) {
-            go = true;
-            mul = albedo;
-            if (h.mat_kind == RT_MAT_LAMBERTIAN) {
-                const bool to_light = rng.next() < 0.5f;
-                LightPick lp{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                if (to_light) lp = lights_pick(recs, Y, rng);
-                scatter_lambert(recs, Y, h, albedo, to_light, lp, rng, nd, mul, go);
-            } else {
-                scatter_specular(h, r.d, rng, nd, mul, ntime);
-            }
-            ++depth;
-        }
+    if (fate == DIFFUSE) {
+        const bool to_light = rng.next() < 0.5f;
+        LightPick lp{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (to_light) lp = lights_pick(recs, Y, rng);
+        scatter_lambert(recs, Y, h, albedo, to_light, lp, rng, nd, mul, go);
     }
+    if (fate == SPECULAR) scatter_specular(h, r.d, rng, nd, mul, ntime);
+    depth += go ? 1 : 0;
     r = Ray{h.p, nd, ntime};
     T = v3(T.x * mul.x, T.y * mul.y, T.z * mul.z);
     // a zero weight is final: every later factor multiplies it
