@@ -354,6 +354,220 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
     flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
 }
 
+// ---------------------------------------------------------------------------
+// render_fast_block_kernel: the same bounce loop, but the four waves of a block REGROUP their 256 paths between the
+// scan and the shade.  A wave shades 64 paths of mixed fate -- some leave the scene, some hit the lamp, some refract,
+// most scatter diffusely towards the light or into the cosine lobe -- one branch after the other, each with a few
+// lanes on: the vector pipes are the limit and half the lanes are off (profiles/r01_headline_fast_path.txt).  Here, after
+// the scan every lane settles what needs no company (miss, lamp, depth limit: the path ends) and names its class:
+//     0 specular (metal / dielectric / isotropic)   1 lambertian sampling a rect light
+//     2 lambertian sampling a sphere light or the cosine lobe                 3 dead
+// The block sorts its paths by class through LDS (two barriers), so a wave shades mostly one class, and the dead lanes
+// end up together in the last wave(s), where the refill from the block's pool runs with every lane on.  The draws keep
+// the reference's order: the coin and the light member are drawn before the exchange, the direction after it.
+// Work unit: a 16x16 pixel tile x a range of samples.
+// ---------------------------------------------------------------------------
+constexpr int XCH_FIELDS = 13;
+template <bool FLAT>
+__global__ __launch_bounds__(256) void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf::Layout Y,
+                                                                RenderArgs A, float *__restrict__ accum)
+{
+    __shared__ float acc[3 * 256];
+    __shared__ uint32_t xch[XCH_FIELDS][256]; // [field][slot]: consecutive lanes, consecutive banks
+    __shared__ int cnt[4][4];                 // [wave][class]
+    __shared__ unsigned pool_next;
+    __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int task = blockIdx.x;
+    for (int k = tid; k < (RT_REC_MAX + 1) * 8; k += 256) lrecs[k] = recs[k];
+    rtf::Regs R;
+    load_records(recs, lane, R);
+
+    const int tile = task / A.n_chunks, chunk = task - tile * A.n_chunks;
+    const int tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x; // 16x16 tiles
+    const int s0 = chunk * A.chunk_samples;
+    const int s1 = min(s0 + A.chunk_samples, A.n_samples);
+    const unsigned total = 256u * (unsigned)((s1 - s0) * A.sub_samples);
+    const float inv_nx = 1.0f / float(A.nx), inv_ny = 1.0f / float(A.ny);
+
+    acc[tid] = 0.0f, acc[256 + tid] = 0.0f, acc[512 + tid] = 0.0f;
+    if (tid == 0) pool_next = 0u;
+    __syncthreads();
+
+    bool alive = false;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1), T = v3(1, 1, 1);
+    float time = 0.0f;
+    Rng rng{0u};
+    int depth = 0, pix = tid;
+
+    for (;;) {
+        // ---- refill: dead lanes (together in the last waves after the regroup) take items from the block's pool --------
+        const unsigned long long dead = __ballot(!alive);
+        if (dead != 0ull) {
+            unsigned base = 0u;
+            if (lane == 0) base = atomicAdd(&pool_next, (unsigned)__popcll(dead)); // may run past `total`; bounded by the host
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base < total) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+                const unsigned item = base + rank;
+                if (!alive && item < total) {
+                    pix = (int)(item & 255u);
+                    const int q = (int)(item >> 8);
+                    const int qs = A.sub_samples == 1 ? q : q / A.sub_samples;
+                    const int sample = A.sample_begin + s0 + qs;
+                    const int sub = q - qs * A.sub_samples;
+                    const int col = tile_x * 16 + (pix & 15), row = tile_y * 16 + (pix >> 4);
+                    if (col < A.nx && row < A.ny) {
+                        rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
+                        const int j = A.ny - 1 - row;
+                        const float u = (float(col) + rng.next()) * inv_nx;
+                        const float v = (float(j) + rng.next()) * inv_ny;
+                        const V3 disk = S.cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
+                        const float time01 = rng.next();
+                        const Ray r = rtf::camera_ray(S.cam, u, v, disk, time01);
+                        o = r.o, d = r.d, time = r.time;
+                        T = v3(1, 1, 1);
+                        depth = 0;
+                        alive = true;
+                    }
+                }
+            }
+        }
+
+        // ---- scan (waves without a live lane skip it) ---------------------------------------------------------------------
+        float t = 0.0f;
+        int rec = -1;
+        if (__any(alive)) rtf::scan<FLAT>(recs, lrecs, Y, Ray{o, d, time}, 0.001f, RT_FLT_MAX, alive, t, rec);
+
+        // ---- what needs no company: the path ends (miss, lamp, depth limit) or gets its class -----------------------------
+        const int src = rec < 0 ? 0 : rec;
+        const uint32_t kw = rtf::sh_u(R.d[7], src); // cross-lane fetches: every lane takes part
+        const int m = Y.materials_base + (int)((kw >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK);
+        const uint32_t mat_kind = rtf::sh_u(R.d[0], m);
+        const V3 mcol = v3(rtf::sh_f(R.d[3], m), rtf::sh_f(R.d[4], m), rtf::sh_f(R.d[5], m));
+        int cls = 3, to_light = 0, light = 0;
+        V3 p = o;
+        if (alive) {
+            if (rec < 0 || !(depth < A.max_depth) || mat_kind == RT_MAT_DIFFUSE_LIGHT) {
+                alive = false;
+                if (rec >= 0 && mat_kind == RT_MAT_DIFFUSE_LIGHT) { // radiance = T * emitted; de_nan, src/vec3.h:184-191
+                    const V3 L = v3(T.x * mcol.x, T.y * mcol.y, T.z * mcol.z);
+                    if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
+                    if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[256 + pix], L.y);
+                    if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[512 + pix], L.z);
+                }
+            } else {
+                ++depth;
+                p = rtf::fma3(t, d, o);
+                cls = 0;
+                if (mat_kind == RT_MAT_LAMBERTIAN) {
+                    cls = 2;
+                    to_light = rng.next() < 0.5f ? 1 : 0;
+                    if (to_light) {
+                        light = rtf::lights_index(Y, rng);
+                        uint32_t lk = RT_REC_LIGHT_NONE; // kind of the member this lane drew (wave-uniform loads)
+                        for (int k = 0; k < Y.n_lights; ++k) lk = light == k ? (recs[8 * (Y.lights_base + k) + 7] & 15u) : lk;
+                        cls = lk == RT_REC_LIGHT_RECT ? 1 : 2;
+                    }
+                }
+            }
+        }
+
+        // ---- regroup by class ----------------------------------------------------------------------------------------------
+        const unsigned long long b0 = __ballot(cls == 0), b1 = __ballot(cls == 1), b2 = __ballot(cls == 2);
+        const unsigned long long mine = cls == 0 ? b0 : cls == 1 ? b1 : cls == 2 ? b2 : ~(b0 | b1 | b2);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+        if (lane < 4) {
+            const unsigned long long bk = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : ~(b0 | b1 | b2);
+            cnt[wave][lane] = __popcll(bk);
+        }
+        __syncthreads();
+        int before = 0, n_dead = 0; // slots of lower classes + slots of my class in lower waves
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const int n = cnt[w2][c];
+                before += (c < cls || (c == cls && w2 < wave)) ? n : 0;
+                n_dead += c == 3 ? n : 0;
+            }
+        }
+        const unsigned pool_now = pool_next; // stable between the two barriers: only the refill changes it
+        const int dst = before + rank;
+        xch[0][dst] = __float_as_uint(p.x), xch[1][dst] = __float_as_uint(p.y), xch[2][dst] = __float_as_uint(p.z);
+        xch[3][dst] = __float_as_uint(d.x), xch[4][dst] = __float_as_uint(d.y), xch[5][dst] = __float_as_uint(d.z);
+        xch[6][dst] = __float_as_uint(time);
+        xch[7][dst] = __float_as_uint(T.x), xch[8][dst] = __float_as_uint(T.y), xch[9][dst] = __float_as_uint(T.z);
+        xch[10][dst] = rng.x;
+        xch[11][dst] = (uint32_t)depth | ((uint32_t)pix << 16) | ((uint32_t)cls << 24) | ((uint32_t)to_light << 26) | ((uint32_t)light << 27);
+        xch[12][dst] = (uint32_t)src;
+        __syncthreads();
+        if (n_dead == 256 && pool_now >= total) break; // the same for every wave of the block
+        p = v3(__uint_as_float(xch[0][tid]), __uint_as_float(xch[1][tid]), __uint_as_float(xch[2][tid]));
+        d = v3(__uint_as_float(xch[3][tid]), __uint_as_float(xch[4][tid]), __uint_as_float(xch[5][tid]));
+        time = __uint_as_float(xch[6][tid]);
+        T = v3(__uint_as_float(xch[7][tid]), __uint_as_float(xch[8][tid]), __uint_as_float(xch[9][tid]));
+        rng.x = xch[10][tid];
+        const uint32_t word = xch[11][tid];
+        const int hit_rec = (int)xch[12][tid];
+        depth = (int)(word & 0xffffu), pix = (int)((word >> 16) & 255u), cls = (int)((word >> 24) & 3u);
+        to_light = (int)((word >> 26) & 1u), light = (int)(word >> 27);
+        alive = cls != 3;
+        o = p;
+
+        // ---- shade: the lanes of a wave now mostly share a class -------------------------------------------------------------
+        if (__any(alive)) {
+            rtf::Surface sf;
+            {   // rtf::build_surface with the point already known; cross-lane fetches by every lane
+                const uint32_t kw2 = rtf::sh_u(R.d[7], hit_rec);
+                const float f0 = rtf::sh_f(R.d[0], hit_rec), f1 = rtf::sh_f(R.d[1], hit_rec), f2 = rtf::sh_f(R.d[2], hit_rec);
+                const float f4 = rtf::sh_f(R.d[4], hit_rec), f5 = rtf::sh_f(R.d[5], hit_rec), f6 = rtf::sh_f(R.d[6], hit_rec);
+                sf.p = p, sf.u = sf.v = 0.0f;
+                if ((kw2 & 15u) == RT_REC_SPHERE) {
+                    const float k = (kw2 & RT_KW_FLIP) ? -f4 : f4;
+                    sf.n = v3((p.x - f0) * k, (p.y - f1) * k, (p.z - f2) * k);
+                } else {
+                    const bool xz = ((kw2 >> RT_KW_AXIS_SHIFT) & 3u) == 1u;
+                    sf.n = v3(f5, xz ? ((kw2 & RT_KW_FLIP) ? -1.0f : 1.0f) : 0.0f, f6);
+                }
+                const int m2 = Y.materials_base + (int)((kw2 >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK);
+                sf.mat_kind = rtf::sh_u(R.d[0], m2);
+                sf.texture = -1;
+                sf.p0 = rtf::sh_f(R.d[2], m2);
+                sf.color = v3(rtf::sh_f(R.d[3], m2), rtf::sh_f(R.d[4], m2), rtf::sh_f(R.d[5], m2));
+            }
+            V3 nd = d, mul = sf.color;
+            float ntime = time;
+            bool go = alive;
+            if (alive & (cls == 0)) rtf::scatter_specular(sf, d, rng, nd, mul, ntime);
+            if (alive & (cls != 0)) {
+                rtf::LightPick lp{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                if (to_light) lp = rtf::light_of_index(recs, Y, light);
+                rtf::scatter_lambert(recs, Y, sf, sf.color, to_light != 0, lp, rng, nd, mul, go);
+            }
+            d = nd, time = ntime;
+            T = v3(T.x * mul.x, T.y * mul.y, T.z * mul.z);
+            alive = go && (T.x != 0.0f || T.y != 0.0f || T.z != 0.0f); // a zero weight is final
+        }
+    }
+
+    // ---- tile sums -> HBM: [A, B, G, R] per pixel (src/main.cpp:238-242), 16 pixels of a row = 256 contiguous bytes ----------
+    {
+        const float inv = 1.0f / (float)A.sub_samples;
+        const int col = tile_x * 16 + (tid & 15), row = tile_y * 16 + (tid >> 4);
+        if (col < A.nx && row < A.ny) {
+            float *dst = accum + 4 * ((size_t)row * A.nx + col);
+            const float v4[4] = {(float)(s1 - s0), acc[512 + tid] * inv, acc[256 + tid] * inv, acc[tid] * inv};
+            if (A.atomic_out) {
+                for (int k = 0; k < 4; ++k) atomicAdd(dst + k, v4[k]);
+            } else {
+                *reinterpret_cast<float4 *>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            }
+        }
+    }
+}
+
 // world->hit() on the record table (what render_fast_kernel's bounces see)
 __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restrict__ recs, const int32_t *__restrict__ rec_user,
                                                          rtf::Layout Y, int n, const float *__restrict__ rays, float t_min,
@@ -784,9 +998,15 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
         if (!accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
         return RT_OK;
     }
+    // the record-table path has two kernels: one wave per 8x8 tile (render_fast_kernel), or one block of four waves per
+    // 16x16 tile that regroups its paths by class between scan and shade (render_fast_block_kernel: no textures, depth
+    // and light list small enough for its packed state word)
+    static const bool block_off = getenv("RT_AMD_NO_BLOCK_KERNEL") != nullptr; // tuning aid
+    const bool block_kernel = use_fast && s->fast_ok && !s->fast_textured && !block_off && p->max_depth < 65536 && s->layout.n_lights <= 32;
+    const int tile_side = block_kernel ? 16 : 8, waves_per_task = block_kernel ? 4 : 1;
     RenderArgs A;
     A.nx = p->nx, A.ny = p->ny;
-    A.tiles_x = (p->nx + 7) / 8, A.tiles_y = (p->ny + 7) / 8;
+    A.tiles_x = (p->nx + tile_side - 1) / tile_side, A.tiles_y = (p->ny + tile_side - 1) / tile_side;
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
     // Tiles differ a lot in cost (glass sphere vs. open front), so the image is cut into many more
     // tasks than the chip holds waves (7168 at 7 waves/SIMD) and the hardware dispatcher balances
@@ -795,11 +1015,16 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     // long paths finishing alone) stays small beside its body.
     int64_t target_tasks = 262144;
     if (const char *e = getenv("RT_AMD_TARGET_TASKS")) target_tasks = atoll(e) > 0 ? atoll(e) : target_tasks; // tuning aid
+    target_tasks /= waves_per_task;
     int64_t want_chunks = (target_tasks + tiles - 1) / tiles;
     int64_t max_chunks = ((int64_t)ns * p->sub_samples + 15) / 16;
     if (want_chunks > max_chunks) want_chunks = max_chunks;
     if (want_chunks > ns) want_chunks = ns;
     if (want_chunks < 1) want_chunks = 1;
+    {   // a task's pool is counted in 32 bits (256 items per sample in the block kernel)
+        const int64_t min_chunks = ((int64_t)ns * p->sub_samples + (1 << 22) - 1) >> 22;
+        if (want_chunks < min_chunks && min_chunks <= ns) want_chunks = min_chunks;
+    }
     A.chunk_samples = (int)((ns + want_chunks - 1) / want_chunks);
     A.n_chunks = (ns + A.chunk_samples - 1) / A.chunk_samples;
     A.sample_begin = p->sample_begin, A.n_samples = ns;
@@ -817,6 +1042,11 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
             hipLaunchKernelGGL(render_fastlanes_kernel<true>, g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
         else
             hipLaunchKernelGGL(render_fastlanes_kernel<false>, g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    } else if (use_fast && block_kernel) {
+        if (s->fast_flat)
+            hipLaunchKernelGGL(render_fast_block_kernel<true>, dim3(A.n_tasks), dim3(256), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+        else
+            hipLaunchKernelGGL(render_fast_block_kernel<false>, dim3(A.n_tasks), dim3(256), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
     } else if (use_fast) {
         const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
         if (s->fast_textured && s->fast_flat)
