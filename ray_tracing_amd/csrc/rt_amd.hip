@@ -368,30 +368,36 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
 // Work unit: a 16x16 pixel tile x a range of samples.
 // ---------------------------------------------------------------------------
 constexpr int XCH_FIELDS = 13;
-template <bool FLAT>
-__global__ __launch_bounds__(256) void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf::Layout Y,
+#ifndef RT_BLOCK_WAVES
+#define RT_BLOCK_WAVES 4
+#endif
+constexpr int BLOCK_WAVES = RT_BLOCK_WAVES;
+// NW waves per block; the tile is (4*NW) x 16 pixels
+template <bool FLAT, int NW>
+__global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf::Layout Y,
                                                                 RenderArgs A, float *__restrict__ accum)
 {
-    __shared__ float acc[3 * 256];
-    __shared__ uint32_t xch[XCH_FIELDS][256]; // [field][slot]: consecutive lanes, consecutive banks
-    __shared__ int cnt[4][4];                 // [wave][class]
+    constexpr int NT = 64 * NW, TW = 4 * NW; // threads = pixels of the tile; tile width
+    __shared__ float acc[3 * NT];
+    __shared__ uint32_t xch[XCH_FIELDS][NT]; // [field][slot]: consecutive lanes, consecutive banks
+    __shared__ int cnt[NW][4];                 // [wave][class]
     __shared__ unsigned pool_next;
     __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int task = blockIdx.x;
-    for (int k = tid; k < (RT_REC_MAX + 1) * 8; k += 256) lrecs[k] = recs[k];
+    for (int k = tid; k < (RT_REC_MAX + 1) * 8; k += NT) lrecs[k] = recs[k];
     rtf::Regs R;
     load_records(recs, lane, R);
 
     const int tile = task / A.n_chunks, chunk = task - tile * A.n_chunks;
-    const int tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x; // 16x16 tiles
+    const int tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x; // TW x 16 tiles
     const int s0 = chunk * A.chunk_samples;
     const int s1 = min(s0 + A.chunk_samples, A.n_samples);
-    const unsigned total = 256u * (unsigned)((s1 - s0) * A.sub_samples);
+    const unsigned total = (unsigned)NT * (unsigned)((s1 - s0) * A.sub_samples);
     const float inv_nx = 1.0f / float(A.nx), inv_ny = 1.0f / float(A.ny);
 
-    acc[tid] = 0.0f, acc[256 + tid] = 0.0f, acc[512 + tid] = 0.0f;
+    acc[tid] = 0.0f, acc[NT + tid] = 0.0f, acc[2 * NT + tid] = 0.0f;
     if (tid == 0) pool_next = 0u;
     __syncthreads();
 
@@ -412,12 +418,12 @@ __global__ __launch_bounds__(256) void render_fast_block_kernel(DevScene S, cons
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
                 const unsigned item = base + rank;
                 if (!alive && item < total) {
-                    pix = (int)(item & 255u);
-                    const int q = (int)(item >> 8);
+                    pix = (int)(item % (unsigned)NT);
+                    const int q = (int)(item / (unsigned)NT);
                     const int qs = A.sub_samples == 1 ? q : q / A.sub_samples;
                     const int sample = A.sample_begin + s0 + qs;
                     const int sub = q - qs * A.sub_samples;
-                    const int col = tile_x * 16 + (pix & 15), row = tile_y * 16 + (pix >> 4);
+                    const int col = tile_x * TW + (pix % TW), row = tile_y * 16 + (pix / TW);
                     if (col < A.nx && row < A.ny) {
                         rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
                         const int j = A.ny - 1 - row;
@@ -454,8 +460,8 @@ __global__ __launch_bounds__(256) void render_fast_block_kernel(DevScene S, cons
                 if (rec >= 0 && mat_kind == RT_MAT_DIFFUSE_LIGHT) { // radiance = T * emitted; de_nan, src/vec3.h:184-191
                     const V3 L = v3(T.x * mcol.x, T.y * mcol.y, T.z * mcol.z);
                     if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
-                    if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[256 + pix], L.y);
-                    if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[512 + pix], L.z);
+                    if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[NT + pix], L.y);
+                    if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[2 * NT + pix], L.z);
                 }
             } else {
                 ++depth;
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(256) void render_fast_block_kernel(DevScene S, cons
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) {
+            for (int w2 = 0; w2 < NW; ++w2) {
                 const int n = cnt[w2][c];
                 before += (c < cls || (c == cls && w2 < wave)) ? n : 0;
                 n_dead += c == 3 ? n : 0;
@@ -500,10 +506,10 @@ __global__ __launch_bounds__(256) void render_fast_block_kernel(DevScene S, cons
         xch[6][dst] = __float_as_uint(time);
         xch[7][dst] = __float_as_uint(T.x), xch[8][dst] = __float_as_uint(T.y), xch[9][dst] = __float_as_uint(T.z);
         xch[10][dst] = rng.x;
-        xch[11][dst] = (uint32_t)depth | ((uint32_t)pix << 16) | ((uint32_t)cls << 24) | ((uint32_t)to_light << 26) | ((uint32_t)light << 27);
+        xch[11][dst] = (uint32_t)depth | ((uint32_t)pix << 16) | ((uint32_t)cls << 25) | ((uint32_t)to_light << 27) | ((uint32_t)light << 28);
         xch[12][dst] = (uint32_t)src;
         __syncthreads();
-        if (n_dead == 256 && pool_now >= total) break; // the same for every wave of the block
+        if (n_dead == NT && pool_now >= total) break; // the same for every wave of the block
         p = v3(__uint_as_float(xch[0][tid]), __uint_as_float(xch[1][tid]), __uint_as_float(xch[2][tid]));
         d = v3(__uint_as_float(xch[3][tid]), __uint_as_float(xch[4][tid]), __uint_as_float(xch[5][tid]));
         time = __uint_as_float(xch[6][tid]);
@@ -511,8 +517,8 @@ __global__ __launch_bounds__(256) void render_fast_block_kernel(DevScene S, cons
         rng.x = xch[10][tid];
         const uint32_t word = xch[11][tid];
         const int hit_rec = (int)xch[12][tid];
-        depth = (int)(word & 0xffffu), pix = (int)((word >> 16) & 255u), cls = (int)((word >> 24) & 3u);
-        to_light = (int)((word >> 26) & 1u), light = (int)(word >> 27);
+        depth = (int)(word & 0xffffu), pix = (int)((word >> 16) & 511u), cls = (int)((word >> 25) & 3u);
+        to_light = (int)((word >> 27) & 1u), light = (int)(word >> 28);
         alive = cls != 3;
         o = p;
 
@@ -552,13 +558,13 @@ __global__ __launch_bounds__(256) void render_fast_block_kernel(DevScene S, cons
         }
     }
 
-    // ---- tile sums -> HBM: [A, B, G, R] per pixel (src/main.cpp:238-242), 16 pixels of a row = 256 contiguous bytes ----------
+    // ---- tile sums -> HBM: [A, B, G, R] per pixel (src/main.cpp:238-242), a tile row is TW x 16 contiguous bytes ----------
     {
         const float inv = 1.0f / (float)A.sub_samples;
-        const int col = tile_x * 16 + (tid & 15), row = tile_y * 16 + (tid >> 4);
+        const int col = tile_x * TW + (tid % TW), row = tile_y * 16 + (tid / TW);
         if (col < A.nx && row < A.ny) {
             float *dst = accum + 4 * ((size_t)row * A.nx + col);
-            const float v4[4] = {(float)(s1 - s0), acc[512 + tid] * inv, acc[256 + tid] * inv, acc[tid] * inv};
+            const float v4[4] = {(float)(s1 - s0), acc[2 * NT + tid] * inv, acc[NT + tid] * inv, acc[tid] * inv};
             if (A.atomic_out) {
                 for (int k = 0; k < 4; ++k) atomicAdd(dst + k, v4[k]);
             } else {
@@ -1002,11 +1008,11 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     // 16x16 tile that regroups its paths by class between scan and shade (render_fast_block_kernel: no textures, depth
     // and light list small enough for its packed state word)
     static const bool block_off = getenv("RT_AMD_NO_BLOCK_KERNEL") != nullptr; // tuning aid
-    const bool block_kernel = use_fast && s->fast_ok && !s->fast_textured && !block_off && p->max_depth < 65536 && s->layout.n_lights <= 32;
-    const int tile_side = block_kernel ? 16 : 8, waves_per_task = block_kernel ? 4 : 1;
+    const bool block_kernel = use_fast && s->fast_ok && !s->fast_textured && !block_off && p->max_depth < 65536 && s->layout.n_lights <= 16;
+    const int tile_w = block_kernel ? 4 * BLOCK_WAVES : 8, tile_h = block_kernel ? 16 : 8, waves_per_task = block_kernel ? BLOCK_WAVES : 1;
     RenderArgs A;
     A.nx = p->nx, A.ny = p->ny;
-    A.tiles_x = (p->nx + tile_side - 1) / tile_side, A.tiles_y = (p->ny + tile_side - 1) / tile_side;
+    A.tiles_x = (p->nx + tile_w - 1) / tile_w, A.tiles_y = (p->ny + tile_h - 1) / tile_h;
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
     // Tiles differ a lot in cost (glass sphere vs. open front), so the image is cut into many more
     // tasks than the chip holds waves (7168 at 7 waves/SIMD) and the hardware dispatcher balances
@@ -1021,8 +1027,8 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     if (want_chunks > max_chunks) want_chunks = max_chunks;
     if (want_chunks > ns) want_chunks = ns;
     if (want_chunks < 1) want_chunks = 1;
-    {   // a task's pool is counted in 32 bits (256 items per sample in the block kernel)
-        const int64_t min_chunks = ((int64_t)ns * p->sub_samples + (1 << 22) - 1) >> 22;
+    {   // a task's pool is counted in 32 bits (up to 512 items per sample in the block kernel)
+        const int64_t min_chunks = ((int64_t)ns * p->sub_samples + (1 << 21) - 1) >> 21;
         if (want_chunks < min_chunks && min_chunks <= ns) want_chunks = min_chunks;
     }
     A.chunk_samples = (int)((ns + want_chunks - 1) / want_chunks);
@@ -1044,9 +1050,9 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
             hipLaunchKernelGGL(render_fastlanes_kernel<false>, g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
     } else if (use_fast && block_kernel) {
         if (s->fast_flat)
-            hipLaunchKernelGGL(render_fast_block_kernel<true>, dim3(A.n_tasks), dim3(256), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
         else
-            hipLaunchKernelGGL(render_fast_block_kernel<false>, dim3(A.n_tasks), dim3(256), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
     } else if (use_fast) {
         const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
         if (s->fast_textured && s->fast_flat)
