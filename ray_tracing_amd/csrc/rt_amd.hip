@@ -367,7 +367,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
 // the reference's order: the coin and the light member are drawn before the exchange, the direction after it.
 // Work unit: a 16x16 pixel tile x a range of samples.
 // ---------------------------------------------------------------------------
-constexpr int XCH_FIELDS = 13;
 #ifndef RT_BLOCK_WAVES
 #define RT_BLOCK_WAVES 4
 #endif
@@ -379,8 +378,8 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
 {
     constexpr int NT = 64 * NW, TW = 4 * NW; // threads = pixels of the tile; tile width
     __shared__ float acc[3 * NT];
-    __shared__ uint32_t xch[XCH_FIELDS][NT]; // [field][slot]: consecutive lanes, consecutive banks
-    __shared__ int cnt[NW][4];                 // [wave][class]
+    __shared__ uint4 xch[3][NT]; // the path state in three 16-byte pieces, [piece][slot]
+    __shared__ int4 cnt[NW];     // [wave].{x,y,z,w} = lanes of class 0..3
     __shared__ unsigned pool_next;
     __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -484,39 +483,33 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
         const unsigned long long b0 = __ballot(cls == 0), b1 = __ballot(cls == 1), b2 = __ballot(cls == 2);
         const unsigned long long mine = cls == 0 ? b0 : cls == 1 ? b1 : cls == 2 ? b2 : ~(b0 | b1 | b2);
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-        if (lane < 4) {
-            const unsigned long long bk = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : ~(b0 | b1 | b2);
-            cnt[wave][lane] = __popcll(bk);
-        }
+        if (lane == 0) cnt[wave] = make_int4(__popcll(b0), __popcll(b1), __popcll(b2), 64 - __popcll(b0 | b1 | b2));
         __syncthreads();
         int before = 0, n_dead = 0; // slots of lower classes + slots of my class in lower waves
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int w2 = 0; w2 < NW; ++w2) {
-                const int n = cnt[w2][c];
-                before += (c < cls || (c == cls && w2 < wave)) ? n : 0;
-                n_dead += c == 3 ? n : 0;
-            }
+        for (int w2 = 0; w2 < NW; ++w2) {
+            const int4 n = cnt[w2];
+            const int lower = (cls > 0 ? n.x : 0) + (cls > 1 ? n.y : 0) + (cls > 2 ? n.z : 0);
+            const int same = cls == 0 ? n.x : cls == 1 ? n.y : cls == 2 ? n.z : n.w;
+            before += lower + (w2 < wave ? same : 0);
+            n_dead += n.w;
         }
         const unsigned pool_now = pool_next; // stable between the two barriers: only the refill changes it
         const int dst = before + rank;
-        xch[0][dst] = __float_as_uint(p.x), xch[1][dst] = __float_as_uint(p.y), xch[2][dst] = __float_as_uint(p.z);
-        xch[3][dst] = __float_as_uint(d.x), xch[4][dst] = __float_as_uint(d.y), xch[5][dst] = __float_as_uint(d.z);
-        xch[6][dst] = __float_as_uint(time);
-        xch[7][dst] = __float_as_uint(T.x), xch[8][dst] = __float_as_uint(T.y), xch[9][dst] = __float_as_uint(T.z);
-        xch[10][dst] = rng.x;
-        xch[11][dst] = (uint32_t)depth | ((uint32_t)pix << 16) | ((uint32_t)cls << 25) | ((uint32_t)to_light << 27) | ((uint32_t)light << 28);
-        xch[12][dst] = (uint32_t)src;
+        // (the ray's time is not carried: nothing the record table can hold -- static spheres and rects -- reads it)
+        const uint32_t packed = (uint32_t)depth | ((uint32_t)pix << 16) | ((uint32_t)cls << 25) | ((uint32_t)to_light << 27) | ((uint32_t)light << 28);
+        xch[0][dst] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(d.x));
+        xch[1][dst] = make_uint4(__float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(T.x), __float_as_uint(T.y));
+        xch[2][dst] = make_uint4(__float_as_uint(T.z), rng.x, packed, (uint32_t)src);
         __syncthreads();
         if (n_dead == NT && pool_now >= total) break; // the same for every wave of the block
-        p = v3(__uint_as_float(xch[0][tid]), __uint_as_float(xch[1][tid]), __uint_as_float(xch[2][tid]));
-        d = v3(__uint_as_float(xch[3][tid]), __uint_as_float(xch[4][tid]), __uint_as_float(xch[5][tid]));
-        time = __uint_as_float(xch[6][tid]);
-        T = v3(__uint_as_float(xch[7][tid]), __uint_as_float(xch[8][tid]), __uint_as_float(xch[9][tid]));
-        rng.x = xch[10][tid];
-        const uint32_t word = xch[11][tid];
-        const int hit_rec = (int)xch[12][tid];
+        const uint4 q0 = xch[0][tid], q1 = xch[1][tid], q2 = xch[2][tid];
+        p = v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+        d = v3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+        T = v3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+        rng.x = q2.y;
+        const uint32_t word = q2.z;
+        const int hit_rec = (int)q2.w;
         depth = (int)(word & 0xffffu), pix = (int)((word >> 16) & 511u), cls = (int)((word >> 25) & 3u);
         to_light = (int)((word >> 27) & 1u), light = (int)(word >> 28);
         alive = cls != 3;
