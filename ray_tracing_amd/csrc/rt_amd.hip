@@ -750,7 +750,7 @@ struct rt_scene {
     // register-resident form (rt_records.h), when the scene fits
     bool fast_ok = false;
     bool fast_textured = false; // some material's texture is not a constant
-    bool fast_flat = false;     // the record stream holds no box records
+    bool fast_flat = false;     // the record stream holds no box records and is stored in runs
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     const char *fast_why = "";
     rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0};
@@ -951,7 +951,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     s->d_records = (uint32_t *)(b + parts[8].off);
     s->d_rec_user = (int32_t *)(b + parts[9].off);
     s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights, {tab.run[0], tab.run[1], tab.run[2], tab.run[3]}, tab.n_runs, tab.n_spheres};
-    s->fast_flat = fast_ok && tab.flat != 0;
+    s->fast_flat = fast_ok && tab.flat != 0 && tab.n_runs > 0; // the run scan; else the generic one (it also walks flat streams)
     *out = s;
     return RT_OK;
 }

@@ -1,26 +1,22 @@
-// rt_fast.hpp -- the render path for scenes that fit the register-resident record
-// table (rt_records.h): same algorithm and same random-draw order as rt_device.hpp,
-// different machine mapping.
+// rt_fast.hpp -- the render path for scenes that fit the record table (rt_records.h): same algorithm and same
+// random-draw order as rt_device.hpp, different machine mapping.
 //
-//   * The scene is 8 VGPRs: lane L holds record L.  The scan reads record i (a
-//     wave-uniform index) with v_readlane: scene data reaches the VALU as SGPR
-//     operands without a memory access, so the inner loop has no load latency at all.
-//   * During the scan a lane keeps only (t, record index) of its closest hit.  The
-//     hit point, normal and material are built once per ray afterwards: the lane
-//     fetches the winning record and its material record with ds_bpermute.
-//   * Spheres are stored in world space (a rigid chain is folded into the centre),
-//     rect records carry their world normal, p = o + t*d is evaluated on the world
-//     ray: instance chains cost nothing outside the boxes and rects under them.
-//   * Arithmetic is hardware-rate: v_rcp/v_sqrt/v_rsq/v_sin/v_cos/v_log (about 1 ulp)
-//     and FMA contraction, 1/d hoisted per ray.  Results therefore differ from the
-//     reference in the last bits; the bit-exact path (rt_device.hpp) remains the one
-//     that rt_trace_rays uses by default, and tests/test_gpu_parity.py compares the
-//     two paths with each other, with the oracle on the same random stream, and
-//     with the reference's converged image.
-//   * Comparisons are written in their positive form (t >= t_min && t <= t_max ...)
-//     so that a NaN never counts as a hit; the reference's negative forms accept a
-//     NaN t, which only arises for a ray origin exactly on a primitive's plane with a
-//     direction exactly parallel to it.
+//   * The scene is a table of at most 64 records of 32 bytes.  The scan walks it with a wave-uniform index, so
+//     scene data is the same for all 64 lanes and no lane computes an address: small scenes (stored flat and in
+//     runs, rt_records.cpp) read their records from a copy in LDS with broadcast reads and test a rect with one
+//     block of v_cmpx instructions (rect_update_v); larger ones use scalar loads with the next record in flight.
+//   * Lane L of every wave also holds record L in 8 VGPRs.  During the scan a lane keeps only (t, record index)
+//     of its closest hit; the hit point, normal and material are built once per ray afterwards: the lane fetches
+//     the winning record and its material record with ds_bpermute.
+//   * Spheres are stored in world space (a rigid chain is folded into the centre), rect records carry their world
+//     normal, p = o + t*d is evaluated on the world ray: instance chains cost one ray transform per chain.
+//   * Arithmetic is hardware-rate: v_rcp/v_sqrt/v_rsq/v_sin/v_cos/v_log (about 1 ulp) and FMA contraction, 1/d
+//     hoisted per ray.  Results therefore differ from the reference in the last bits; the bit-exact path
+//     (rt_device.hpp) remains the one that rt_trace_rays uses by default, and tests/test_gpu_parity.py compares the
+//     two paths with each other, with the oracle on the same random stream, and with the reference's converged image.
+//   * Comparisons are written in their positive form (t >= t_min && t <= t_max ...) so that a NaN never counts as
+//     a hit; the reference's negative forms accept a NaN t, which only arises for a ray origin exactly on a
+//     primitive's plane with a direction exactly parallel to it.
 #ifndef RT_FAST_HPP_
 #define RT_FAST_HPP_
 
@@ -171,7 +167,6 @@ RTF_DEV bool rect_in(const SRec &c, float ok, float ik, float oa, float da, floa
                        [ok] "v"(ok), [ik] "v"(ik), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob), [db] "v"(db)                \
                      : "vcc");                                                                                           \
     }
-RTF_RECT_UPDATE(rect_update, "s")   // record fields in SGPRs (scalar loads)
 RTF_RECT_UPDATE(rect_update_v, "v") // record fields in VGPRs (broadcast reads from LDS)
 
 // `count` rect records of one chain and axis from record `index` on: nothing to decode, the loop is fetch + test.
@@ -235,53 +230,12 @@ RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs,
     best_rec = alive ? best_rec : -1;
 }
 
-// The scan of a FLAT stream (no box records; stored chain by chain, rt_records.cpp).  Dead lanes run along (their rays
-// are finite leftovers); `alive` is applied once at the end.  No software prefetch: eight waves per SIMD hide the scalar
-// load, and rotating a prefetched record through copies costs seven scalar moves per record.
-RTF_DEV void scan_flat(const uint32_t *__restrict__ recs, const Layout &Y, const Ray &wr, float t_min, float t_max, bool alive,
-                       float &best_t, int &best_rec)
-{
-    best_t = t_max;
-    best_rec = -1;
-    LocalRay l;
-    set_local(l, wr.o, wr.d);
-    const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
-    for (int i = 0; i < Y.n_stream; ++i) {
-        const SRec c = load_rec(recs, i);
-        const uint32_t kw = c.d[7];
-        if (kw & RT_KW_ENTER) apply_chain(recs, (kw >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK, wr, l);
-        const uint32_t kind_axis = kw & 0x3fu; // kind | axis << 4
-        if (kind_axis == (RT_REC_RECT | (0u << RT_KW_AXIS_SHIFT))) {
-            rect_update(sf(c, 4), sf(c, 0), sf(c, 1), sf(c, 2), sf(c, 3), t_min, i, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, best_t, best_rec);
-        } else if (kind_axis == (RT_REC_RECT | (1u << RT_KW_AXIS_SHIFT))) {
-            rect_update(sf(c, 4), sf(c, 0), sf(c, 1), sf(c, 2), sf(c, 3), t_min, i, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, best_t, best_rec);
-        } else if (kind_axis == (RT_REC_RECT | (2u << RT_KW_AXIS_SHIFT))) {
-            rect_update(sf(c, 4), sf(c, 0), sf(c, 1), sf(c, 2), sf(c, 3), t_min, i, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best_t, best_rec);
-        } else { // sphere, world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree
-            const V3 oc = v3(wr.o.x - sf(c, 0), wr.o.y - sf(c, 1), wr.o.z - sf(c, 2));
-            const float radius = sf(c, 3);
-            const float b = fdot(oc, wr.d);
-            const float cc = fmaf(-radius, radius, fdot(oc, oc));
-            const float disc = fmaf(b, b, -(w_dd * cc));
-            const float sq = fsqrt(disc);
-            const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
-            const bool in1 = (t1 < t_max) & (t1 > t_min), in2 = (t2 < t_max) & (t2 > t_min);
-            const float t = in1 ? t1 : t2;
-            const bool in = (disc > 0.0f) & (in1 | in2) & (t <= best_t);
-            best_t = in ? t : best_t;
-            best_rec = in ? i : best_rec;
-        }
-    }
-    best_rec = alive ? best_rec : -1;
-}
-
 template <bool FLAT>
 RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min, float t_max,
                   bool alive, float &best_t, int &best_rec)
 {
-    if (FLAT) {
-        if (Y.n_runs > 0) scan_runs(recs, lrecs, Y, wr, t_min, t_max, alive, best_t, best_rec);
-        else scan_flat(recs, Y, wr, t_min, t_max, alive, best_t, best_rec);
+    if (FLAT) { // the stream is stored in runs (the host only asks for FLAT when it is)
+        scan_runs(recs, lrecs, Y, wr, t_min, t_max, alive, best_t, best_rec);
         return;
     }
     best_t = t_max;

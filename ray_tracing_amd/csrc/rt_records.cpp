@@ -2,6 +2,7 @@
 #include "rt_records.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -96,7 +97,8 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             const rt_prim &p = d->prims[d->entries[e].a];
             n_leaf_records += p.kind == RT_PRIM_GROUP ? p.count : 1;
         }
-    const bool keep_inner = n_leaf_records > RT_REC_FLAT_LEAVES;
+    // (RT_AMD_RECORDS_KEEP_BOXES: test aid -- small scenes keep their box records too, so the tests reach the generic scan)
+    const bool keep_inner = n_leaf_records > RT_REC_FLAT_LEAVES || getenv("RT_AMD_RECORDS_KEEP_BOXES") != nullptr;
     for (int e = 0; e < d->n_entries; ++e) {
         map[e] = n_stream;
         const rt_entry &en = d->entries[e];
@@ -228,8 +230,8 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
     }
     // A flat stream is stored in runs: chain by chain (world space first), within a chain the rects by axis, and all
     // spheres (world space) at the end.  The scan (rt_fast.hpp) then runs one tight loop per run, with nothing to decode
-    // per record; the run lengths travel in the kernel arguments.  The first record of a run under an instance chain
-    // also carries RT_KW_ENTER, for the scan that decodes record by record (more than RT_REC_MAX_RUNS chains).
+    // per record; the run lengths travel in the kernel arguments.  (More than RT_REC_MAX_RUNS chains: n_runs = 0 and the
+    // generic scan, which decodes every record, is used.)
     // The order of a flat stream only decides which of two hits at the SAME distance is kept.
     if (out->flat) {
         std::vector<int> order(n_stream);
@@ -257,7 +259,6 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
                 continue;
             }
             const bool first = i == 0 || chain_of(out->rec[i - 1]) != chain_of(r);
-            if (first && chain_of(r) != 0u) r[7] |= RT_KW_ENTER;
             if (first) {
                 if (n_runs == RT_REC_MAX_RUNS) { fits = false; continue; }
                 chains[n_runs++] = chain_of(r);

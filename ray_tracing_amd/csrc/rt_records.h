@@ -49,7 +49,6 @@ enum rt_rec_kind {
 #define RT_KW_CHAIN_MASK 0x1ffu
 #define RT_KW_MAT_SHIFT 18
 #define RT_KW_MAT_MASK 0xffu
-#define RT_KW_ENTER (1u << 26) /* flat streams (stored chain by chain): first record of a run under an instance chain */
 
 typedef struct rt_record_table {
     uint32_t rec[RT_REC_MAX + 1][8]; /* one spare record: the scan prefetches record i+1 */
@@ -62,7 +61,7 @@ typedef struct rt_record_table {
     int32_t flat;                /* 1: the stream holds no inner (box) records */
     /* flat streams are stored in RUNS: for each instance chain (world space first) its rects by axis (xy, xz, yz), then
      * all spheres (world space).  run[r] = chain word << 15 | n_xy << 10 | n_xz << 5 | n_yz.  n_runs == 0: the stream
-     * has more than RT_REC_MAX_RUNS chains and the scan decodes every record instead. */
+     * has more than RT_REC_MAX_RUNS chains (or a run above 31 records); the generic scan then decodes every record. */
     uint32_t run[4];
     int32_t n_runs, n_spheres;
 } rt_record_table;

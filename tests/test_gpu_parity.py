@@ -140,6 +140,26 @@ def test_render_matches_oracle_on_the_same_stream(nx, ny, ns, nss, depth, path):
     sc.close()
 
 
+def test_generic_scan_with_box_records_matches_oracle(monkeypatch):
+    """Scenes of more than 16 primitives keep their box records in the record table and are scanned by the generic loop
+    (lanes that miss a box skip its subtree).  No built-in scene of that size fits the table, so the Cornell box is built
+    with its boxes kept (RT_AMD_RECORDS_KEEP_BOXES) and must give the oracle's image on the same random stream."""
+    monkeypatch.setenv("RT_AMD_RECORDS_KEEP_BOXES", "1")
+    nx, ny, ns = 48, 40, 6
+    hs = HostScene("cornell_box", nx / ny)
+    sc = Scene(hs, 0)
+    monkeypatch.delenv("RT_AMD_RECORDS_KEEP_BOXES")
+    plain = Scene(hs, 0)
+    assert sc.info(_capi.RT_INFO_RECORDS) > plain.info(_capi.RT_INFO_RECORDS)  # the 7 boxes of the tree are in the table
+    sc.set_path(render=_capi.RT_PATH_FAST)
+    g = gpu_render(sc, nx, ny, 0, ns, max_depth=50, seed=3)
+    c, _, _ = O.render(hs, nx, ny, 0, ns, 1, 50, O.ORC_RNG_COUNTER, 3, 8)
+    close = np.isclose(g[..., 1:], c[..., 1:], rtol=1e-3, atol=1e-4).all(axis=-1)
+    assert close.mean() >= 0.97, f"only {close.mean():.4f} of pixels agree"
+    assert np.allclose(g[..., 1:].mean(axis=(0, 1)), c[..., 1:].mean(axis=(0, 1)), rtol=1e-2, atol=1e-5)
+    sc.close(), plain.close()
+
+
 def test_render_is_deterministic_and_sample_ranges_add_up(cornell_gpu):
     """Disjoint sample ranges (what different GPUs render) sum to the full render: the paths are
     keyed by (pixel, sample), not by who traces them.  Float sums differ only in order."""
