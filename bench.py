@@ -42,7 +42,7 @@ def cpu_baseline():
     cores = min(16, os.cpu_count() or 1)
     if os.path.exists(ref):
         runs = []
-        for threads, spp in ((1, 64), (cores, 128)):
+        for threads, spp in ((1, 128), (cores, 512)):  # about 18 s of CPU work on the GPU box
             out = subprocess.run([ref, "-w", "256", "-h", "256", "-s", str(spp), "-r", str(DEPTH), "-t", str(threads),
                                   "-o", "/tmp/rt_ref_bench.png"], capture_output=True, text=True, cwd="/tmp", timeout=600)
             m = re.search(r"Time:\s*([0-9.]+)\s*ms", out.stdout)
