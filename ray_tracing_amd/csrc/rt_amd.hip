@@ -881,11 +881,12 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     const bool ordered = rt_order_build(d, order, &tree_depth);
     // no record table: the per-lane fast path, with its own tree (rt_bvh.h) and the light records only
     std::vector<rt_bvh_node> bvh;
+    std::vector<rt_leaf> leaves;
     std::vector<rt_prim> fprims;
     int bvh_depth = 0;
-    const bool lanes_ok = !fast_ok && rt_bvh_build(d, bvh, fprims, &bvh_depth) && rt_records_build_lights(d, &tab) != 0;
-    if (!lanes_ok) bvh.clear(), fprims.clear();
-    part parts[13] = {
+    const bool lanes_ok = !fast_ok && rt_bvh_build(d, bvh, leaves, fprims, &bvh_depth) && rt_records_build_lights(d, &tab) != 0;
+    if (!lanes_ok) bvh.clear(), leaves.clear(), fprims.clear();
+    part parts[14] = {
         {d->entries, sizeof(rt_entry) * (size_t)d->n_entries, 0},
         {d->prims, sizeof(rt_prim) * (size_t)d->n_prims, 0},
         {d->xforms, sizeof(rt_xform) * (size_t)d->n_xforms, 0},
@@ -899,6 +900,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         {order.data(), sizeof(int32_t) * order.size(), 0},
         {bvh.data(), sizeof(rt_bvh_node) * bvh.size(), 0},
         {fprims.data(), sizeof(rt_prim) * fprims.size(), 0},
+        {leaves.data(), sizeof(rt_leaf) * leaves.size(), 0},
     };
     size_t total = 0;
     for (part &p : parts) {
@@ -939,6 +941,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     D.ord = (const int2 *)(b + parts[10].off);
     D.bvh = lanes_ok ? (const rt_bvh_node *)(b + parts[11].off) : nullptr;
     D.fprims = lanes_ok ? (const rt_prim *)(b + parts[12].off) : nullptr;
+    D.leaves = lanes_ok ? (const rt_leaf *)(b + parts[13].off) : nullptr;
     D.ordered = ordered ? 1 : 0;
     D.n_entries = d->n_entries, D.n_lights = d->n_lights;
     D.cam = d->camera;

@@ -109,9 +109,15 @@ bool world_box(const rt_scene_desc *d, const rt_prim &p, Box &out)
     return out.finite();
 }
 
+// the tree is built with float boxes and references to primitives; rt_bvh_build packs it afterwards
+struct Node32 {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t ref0, ref1;
+};
+
 struct Builder {
     std::vector<Item> items;
-    std::vector<rt_bvh_node> *nodes;
+    std::vector<Node32> *nodes;
     int max_depth = 0;
     bool ok = true;
 
@@ -128,7 +134,7 @@ struct Builder {
         max_depth = std::max(max_depth, depth);
         if (depth > RT_BVH_MAX_DEPTH) return ok = false, 0;
         const int32_t me = (int32_t)nodes->size();
-        nodes->push_back(rt_bvh_node{});
+        nodes->push_back(Node32{});
         const size_t n = b - a;
         Box cb;
         cb.clear();
@@ -198,21 +204,57 @@ struct Builder {
         for (size_t i = mid; i < b; ++i) b1.add(items[i].b);
         const int32_t r0 = mid - a == 1 ? ~items[a].prim : build(a, mid, depth + 1);
         const int32_t r1 = b - mid == 1 ? ~items[mid].prim : build(mid, b, depth + 1);
-        rt_bvh_node &nd = (*nodes)[me];
+        Node32 &nd = (*nodes)[me];
         for (int k = 0; k < 3; ++k) nd.lo0[k] = b0.lo[k], nd.hi0[k] = b0.hi[k], nd.lo1[k] = b1.lo[k], nd.hi1[k] = b1.hi[k];
         nd.ref0 = r0, nd.ref1 = r1;
         return me;
     }
 };
 
+// float -> IEEE half, rounded towards -inf (up = false) or +inf (up = true)
+uint16_t to_half(float x, bool up)
+{
+    if (std::isnan(x)) return 0x7e00;
+    const bool neg = std::signbit(x);
+    const double a = std::fabs((double)x);
+    const bool away = neg ? !up : up; // round the magnitude away from zero?
+    uint16_t h;
+    if (a == 0.0) {
+        h = 0;
+    } else if (a > 65504.0) {
+        h = away ? 0x7c00 : 0x7bff; // inf, or the largest finite half
+    } else {
+        int e;
+        const double m = std::frexp(a, &e); // a = m * 2^e, m in [0.5, 1)
+        int he = e - 1 + 15;                // biased exponent of the normal form 1.f * 2^(e-1)
+        double frac;                        // mantissa in units of the last place
+        if (he <= 0) {                      // subnormal half: units of 2^-24
+            frac = a * 16777216.0;
+            he = 0;
+        } else {
+            frac = (m * 2.0 - 1.0) * 1024.0;
+        }
+        double fl = std::floor(frac);
+        if (away && fl != frac) fl += 1.0;
+        uint32_t bits = ((uint32_t)he << 10) + (uint32_t)fl; // a carry out of the mantissa moves into the exponent
+        if (bits >= 0x7c00u) bits = away ? 0x7c00u : 0x7bffu;
+        h = (uint16_t)bits;
+    }
+    return (uint16_t)(h | (neg ? 0x8000u : 0u));
+}
+
 } // namespace
 
-bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::vector<rt_prim> &prims, int *depth)
+bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::vector<rt_leaf> &leaves, std::vector<rt_prim> &prims,
+                  int *depth)
 {
     nodes.clear();
+    leaves.clear();
     prims.assign(d->prims, d->prims + d->n_prims);
+    if (d->n_chains > (1 << 24)) return false;
+    std::vector<Node32> tree;
     Builder B;
-    B.nodes = &nodes;
+    B.nodes = &tree;
     std::vector<char> seen((size_t)d->n_prims, 0);
     auto add_item = [&](int32_t pi) -> bool {
         // A one-primitive bvh_node holds its primitive twice (src/bvh.h:98-101) and the reference visits it twice.  For a
@@ -254,16 +296,41 @@ bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::
         }
     }
     if (B.items.empty()) return false;
-    nodes.reserve(B.items.size());
+    tree.reserve(B.items.size());
     if (B.items.size() == 1) { // a root with one child
-        rt_bvh_node nd{};
-        for (int k = 0; k < 3; ++k) nd.lo0[k] = B.items[0].b.lo[k], nd.hi0[k] = B.items[0].b.hi[k], nd.lo1[k] = 1.0f, nd.hi1[k] = -1.0f;
+        Node32 nd{};
+        for (int k = 0; k < 3; ++k) nd.lo0[k] = B.items[0].b.lo[k], nd.hi0[k] = B.items[0].b.hi[k], nd.lo1[k] = 0.0f, nd.hi1[k] = 0.0f;
         nd.ref0 = ~B.items[0].prim, nd.ref1 = RT_BVH_NONE;
-        nodes.push_back(nd);
+        tree.push_back(nd);
         *depth = 1;
-        return true;
+    } else {
+        B.build(0, B.items.size(), 1);
+        *depth = B.max_depth;
+        if (!B.ok) return false;
     }
-    B.build(0, B.items.size(), 1);
-    *depth = B.max_depth;
-    return B.ok;
+    // pack: leaves in the order the tree names them, boxes as halves rounded outwards
+    auto leaf_of = [&](int32_t ref) -> int32_t {
+        if (ref >= 0 || ref == RT_BVH_NONE) return ref;
+        const int32_t pi = ~ref;
+        const rt_prim &p = prims[pi];
+        const rt_prim &shape = p.kind == RT_PRIM_MEDIUM ? prims[p.first] : p;
+        rt_leaf lf{};
+        for (int k = 0; k < 5; ++k) lf.f[k] = p.kind == RT_PRIM_MEDIUM ? 0.0f : p.f[k];
+        lf.kind_chain = (uint32_t)p.kind | ((uint32_t)shape.chain << 8);
+        lf.prim = pi;
+        lf.visits = p.reserved;
+        leaves.push_back(lf);
+        return ~(int32_t)(leaves.size() - 1);
+    };
+    nodes.resize(tree.size());
+    for (size_t i = 0; i < tree.size(); ++i) {
+        const Node32 &n = tree[i];
+        rt_bvh_node &o = nodes[i];
+        for (int k = 0; k < 3; ++k) {
+            o.lo0[k] = to_half(n.lo0[k], false), o.hi0[k] = to_half(n.hi0[k], true);
+            o.lo1[k] = to_half(n.lo1[k], false), o.hi1[k] = to_half(n.hi1[k], true);
+        }
+        o.ref0 = leaf_of(n.ref0), o.ref1 = leaf_of(n.ref1);
+    }
+    return true;
 }

@@ -16,23 +16,38 @@
 
 #include "../../include/rt_amd.h"
 
-/* child reference: >= 0 inner node index; < 0 leaf: ~ref is an rt_prim index; RT_BVH_NONE: no child */
+/* child reference: >= 0 inner node index; < 0 leaf: ~ref is an rt_leaf index; RT_BVH_NONE: no child */
 #define RT_BVH_NONE ((int32_t)0x80000000)
 #define RT_BVH_MAX_DEPTH 24 /* pending far children per lane: the stack in LDS */
 
+/* Inner node, 32 bytes (two dwordx4 loads from one cache line): the boxes of both children as IEEE half floats, rounded
+ * outwards (lo down, hi up; beyond the half range they become -inf / +inf), and the two child references.  The walk
+ * feeds the halves straight into v_fma_mix_f32 (t = half(lo) * (1/d) - o/d in one instruction), so the halved node
+ * costs no decoding.  A box that is a little too large only costs a visit. */
 typedef struct rt_bvh_node {
-    float   lo0[3]; int32_t ref0;
-    float   hi0[3]; int32_t ref1;
-    float   lo1[3]; int32_t pad0;
-    float   hi1[3]; int32_t pad1;
-} rt_bvh_node; /* 64 bytes: four dwordx4 loads from one or two cache lines */
+    uint16_t lo0[3], hi0[3];
+    int32_t  ref0;
+    uint16_t lo1[3], hi1[3];
+    int32_t  ref1;
+} rt_bvh_node;
+
+/* Leaf, 32 bytes, stored in the order the tree's leaves are met (neighbours in space are neighbours in memory):
+ * what the intersection test reads, and the rt_prim the hit is built from afterwards.
+ *   sphere: f = cx cy cz r    rect: f = a0 a1 b0 b1 k    moving sphere, constant_medium: the test reads prims[prim] */
+typedef struct rt_leaf {
+    float    f[5];
+    uint32_t kind_chain; /* rt_prim_kind | instance chain << 8 (of the shape; 0 = world space) */
+    int32_t  prim;       /* index into the primitive table returned by rt_bvh_build */
+    int32_t  visits;     /* times the reference's tree visits this primitive (rt_bvh.cpp) */
+} rt_leaf;
 
 /* Builds the tree over the primitives the entry array names (each once; the members of a list -- box faces -- are
  * items of their own, so a leaf is always one sphere, one rect or one constant_medium).  `prims` receives the
- * primitive table the tree's leaf references index: a copy of d->prims in which spheres under a rigid instance chain
- * are moved to world space (chain 0; not those whose texture reads (u,v), which is defined in the sphere's own frame).
- * Returns false when it cannot (a depth bound it could not keep, non-finite boxes); the caller then has no fast
- * path for large scenes. */
-bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::vector<rt_prim> &prims, int *depth);
+ * primitive table rt_leaf.prim indexes: a copy of d->prims in which spheres under a rigid instance chain are moved to
+ * world space (chain 0; not those whose texture reads (u,v), which is defined in the sphere's own frame).
+ * Returns false when it cannot (a depth bound it could not keep, non-finite boxes, more than 2^24 chains); the caller
+ * then has no fast path for large scenes. */
+bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::vector<rt_leaf> &leaves, std::vector<rt_prim> &prims,
+                  int *depth);
 
 #endif

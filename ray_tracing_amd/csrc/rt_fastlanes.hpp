@@ -17,6 +17,8 @@
 #ifndef RT_FASTLANES_HPP_
 #define RT_FASTLANES_HPP_
 
+#include <hip/hip_fp16.h>
+
 #include "rt_bvh.h"
 #include "rt_fast.hpp"
 
@@ -110,23 +112,26 @@ RTF_DEV void walk_start(Walk &w, const Ray &wr, float t_max, bool go)
 }
 RTF_DEV int walk_pop(Walk &w, const int *stack) { return w.sp > 0 ? stack[--w.sp * 64] : RT_BVH_NONE; }
 
-// lanes with cur >= 0: both children's boxes of node cur, far bound = best hit so far; nearer child next, the other pushed
+// t of the plane stored as a half in the low / high 16 bits of w: ONE v_fma_mix_f32 (half * float + float)
+RTF_DEV float plane_lo(uint32_t w, float inv, float noi) { return fmaf(__half2float(__ushort_as_half((unsigned short)(w & 0xffffu))), inv, noi); }
+RTF_DEV float plane_hi(uint32_t w, float inv, float noi) { return fmaf(__half2float(__ushort_as_half((unsigned short)(w >> 16))), inv, noi); }
+
+// lanes with cur >= 0: both children's boxes of node cur (32 bytes: half-float boxes, rt_bvh.h), far bound = best hit
+// so far; nearer child next, the other pushed
 RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, int *stack)
 {
     const uint4 *q = reinterpret_cast<const uint4 *>(S.bvh + w.cur);
-    const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+    const uint4 a = q[0], b = q[1]; // {lo.x|lo.y, lo.z|hi.x, hi.y|hi.z, ref} per child
     const V3 i = w.winv, n = w.noi;
-    const float x00 = fmaf(__uint_as_float(a0.x), i.x, n.x), x01 = fmaf(__uint_as_float(a1.x), i.x, n.x);
-    const float y00 = fmaf(__uint_as_float(a0.y), i.y, n.y), y01 = fmaf(__uint_as_float(a1.y), i.y, n.y);
-    const float z00 = fmaf(__uint_as_float(a0.z), i.z, n.z), z01 = fmaf(__uint_as_float(a1.z), i.z, n.z);
-    const float x10 = fmaf(__uint_as_float(a2.x), i.x, n.x), x11 = fmaf(__uint_as_float(a3.x), i.x, n.x);
-    const float y10 = fmaf(__uint_as_float(a2.y), i.y, n.y), y11 = fmaf(__uint_as_float(a3.y), i.y, n.y);
-    const float z10 = fmaf(__uint_as_float(a2.z), i.z, n.z), z11 = fmaf(__uint_as_float(a3.z), i.z, n.z);
+    const float x00 = plane_lo(a.x, i.x, n.x), y00 = plane_hi(a.x, i.y, n.y), z00 = plane_lo(a.y, i.z, n.z);
+    const float x01 = plane_hi(a.y, i.x, n.x), y01 = plane_lo(a.z, i.y, n.y), z01 = plane_hi(a.z, i.z, n.z);
+    const float x10 = plane_lo(b.x, i.x, n.x), y10 = plane_hi(b.x, i.y, n.y), z10 = plane_lo(b.y, i.z, n.z);
+    const float x11 = plane_hi(b.y, i.x, n.x), y11 = plane_lo(b.z, i.y, n.y), z11 = plane_hi(b.z, i.z, n.z);
     const float tn0 = fmaxf(fmax3(fminf(x00, x01), fminf(y00, y01), fminf(z00, z01)), t_min);
     const float tf0 = fminf(fmin3(fmaxf(x00, x01), fmaxf(y00, y01), fmaxf(z00, z01)), w.best_t);
     const float tn1 = fmaxf(fmax3(fminf(x10, x11), fminf(y10, y11), fminf(z10, z11)), t_min);
     const float tf1 = fminf(fmin3(fmaxf(x10, x11), fmaxf(y10, y11), fmaxf(z10, z11)), w.best_t);
-    const int ref0 = (int)a0.w, ref1 = (int)a1.w;
+    const int ref0 = (int)a.w, ref1 = (int)b.w;
     const bool h0 = tf0 >= tn0, h1 = (tf1 >= tn1) & (ref1 != RT_BVH_NONE);
     const bool first0 = tn0 <= tn1;
     const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
@@ -141,12 +146,13 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, int *stack)
     }
 }
 
-// lanes with cur < 0 (and not NONE): primitive ~cur against the lane's ray
+// lanes with cur < 0 (and not NONE): leaf ~cur (rt_bvh.h: 32 bytes, what the test of a sphere or rect reads) against
+// the lane's ray.  best_prim receives the leaf's rt_prim index.
 RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, int *stack)
 {
-    const int leaf = ~w.cur;
-    const rt_prim &pr = S.fprims[leaf];
-    const int chain = pr.kind == RT_PRIM_MEDIUM ? S.fprims[pr.first].chain : pr.chain;
+    const uint4 *q = reinterpret_cast<const uint4 *>(S.leaves + ~w.cur);
+    const uint4 la = q[0], lb = q[1]; // f0 f1 f2 f3 | f4 kind_chain prim visits
+    const int kind = (int)(lb.y & 255u), chain = (int)(lb.y >> 8);
     Ray lr = wr;
     V3 inv = w.winv;
     if (chain != 0) {
@@ -154,33 +160,55 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         inv = rcp3(lr.d);
     }
     float t = 0.0f;
-    int which = leaf;
     bool h;
-    if (pr.kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment)
-        const rt_prim &bp = S.fprims[pr.first];
-        float t1 = 0.0f, t2 = 0.0f;
-        int dummy;
-        h = false;
-        if (simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
-            simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy)) {
-            t1 = fminf(fmaxf(t1, t_min), w.best_t);
-            if (t1 < t2) {
-                t1 = fmaxf(t1, 0.0f);
-                // one draw per visit the reference pays this medium (rt_bvh.cpp: a lone child of a bvh_node is visited
-                // twice); the nearest of the candidates is what its tree keeps
-                float u = rng.next();
-                for (int v = 1; v < pr.reserved; ++v) u = fmaxf(u, rng.next());
-                const float hit_distance = -rcp(pr.f[0]) * __logf(u);
-                t = fmaf(hit_distance, rsq(w.dd), t1);
-                h = true;
+    if (kind == RT_PRIM_SPHERE) { // src/sphere.h:21-59
+        const V3 oc = v3(lr.o.x - __uint_as_float(la.x), lr.o.y - __uint_as_float(la.y), lr.o.z - __uint_as_float(la.z));
+        const float radius = __uint_as_float(la.w);
+        const float b = fdot(oc, lr.d);
+        const float cc = fmaf(-radius, radius, fdot(oc, oc));
+        const float disc = fmaf(b, b, -(w.dd * cc));
+        const float sq = fsqrt(disc);
+        const float t1 = (-b - sq) * w.inv_dd, t2 = (-b + sq) * w.inv_dd;
+        const bool in1 = (t1 < w.best_t) & (t1 > t_min), in2 = (t2 < w.best_t) & (t2 > t_min);
+        t = in1 ? t1 : t2;
+        h = (disc > 0.0f) & (in1 | in2);
+    } else if (kind >= RT_PRIM_XY_RECT && kind <= RT_PRIM_YZ_RECT) { // src/plane.h:9-29, 47-67, 109-129
+        const bool xy = kind == RT_PRIM_XY_RECT, xz = kind == RT_PRIM_XZ_RECT;
+        const float ok = xy ? lr.o.z : xz ? lr.o.y : lr.o.x, ik = xy ? inv.z : xz ? inv.y : inv.x;
+        const float oa = (xy | xz) ? lr.o.x : lr.o.y, da = (xy | xz) ? lr.d.x : lr.d.y;
+        const float ob = xy ? lr.o.y : lr.o.z, db = xy ? lr.d.y : lr.d.z;
+        t = (__uint_as_float(lb.x) - ok) * ik;
+        const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
+        h = (t >= t_min) & (t <= w.best_t) & (a >= __uint_as_float(la.x)) & (a <= __uint_as_float(la.y)) & (b >= __uint_as_float(la.z)) &
+            (b <= __uint_as_float(la.w));
+    } else { // moving sphere, constant_medium: the test reads the primitive itself
+        const rt_prim &pr = S.fprims[(int)lb.z];
+        if (kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment)
+            const rt_prim &bp = S.fprims[pr.first];
+            float t1 = 0.0f, t2 = 0.0f;
+            int dummy;
+            h = false;
+            if (simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
+                simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy)) {
+                t1 = fminf(fmaxf(t1, t_min), w.best_t);
+                if (t1 < t2) {
+                    t1 = fmaxf(t1, 0.0f);
+                    // one draw per visit the reference pays this medium (rt_bvh.cpp: a lone child of a bvh_node is visited
+                    // twice); the nearest of the candidates is what its tree keeps
+                    float u = rng.next();
+                    for (int v = 1; v < (int)lb.w; ++v) u = fmaxf(u, rng.next());
+                    const float hit_distance = -rcp(pr.f[0]) * __logf(u);
+                    t = fmaf(hit_distance, rsq(w.dd), t1);
+                    h = true;
+                }
             }
+        } else {
+            h = plain_t(pr, lr, inv, w.dd, w.inv_dd, t_min, w.best_t, t);
         }
-    } else {
-        h = simple_t(S, leaf, pr, lr, inv, w.dd, w.inv_dd, t_min, w.best_t, t, which);
     }
     const bool take = h & (t <= w.best_t);
     w.best_t = take ? t : w.best_t;
-    w.best_prim = take ? which : w.best_prim;
+    w.best_prim = take ? (int)lb.z : w.best_prim;
     w.cur = walk_pop(w, stack);
 }
 
