@@ -434,6 +434,62 @@ RTF_DEV LightPick lights_pick(const uint32_t *__restrict__ recs, const Layout &Y
     return light_of_index(recs, Y, lights_index(Y, rng));
 }
 
+// Textures for the fast paths: rt::tex_value (src/texture.h, src/perlin.h) with hardware sine and with the perlin
+// loops kept as loops (fully unrolled, the eight corner gradients of seven octaves cost the kernel 50 more registers).
+RTF_DEV float fast_perlin_noise(V3 p) // src/perlin.h:54-121
+{
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const float uu = u * u * (3.0f - 2.0f * u), vv = v * v * (3.0f - 2.0f * v), ww = w * w * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+#pragma nounroll
+    for (int c = 0; c < 8; ++c) {
+        const int di = c >> 2, dj = (c >> 1) & 1, dk = c & 1;
+        const uint32_t h = 1619u * (uint32_t)(i + di) + 31337u * (uint32_t)(j + dj) + 6971u * (uint32_t)(k + dk) + 1013u;
+        int index = (int)h;
+        index ^= (index >> 8);
+        index &= 0xff;
+        const float4 g = rt::k_perlin_gradients[index];
+        const float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
+        accum = fmaf(wi * wj * wk, fmaf(g.z, w - (float)dk, fmaf(g.y, v - (float)dj, g.x * (u - (float)di))), accum);
+    }
+    return accum;
+}
+RTF_DEV float fast_perlin_turb(V3 p) // src/perlin.h:123-136, depth 7
+{
+    float accum = 0.0f, weight = 1.0f;
+#pragma nounroll
+    for (int i = 0; i < 7; ++i) {
+        accum = fmaf(weight, fast_perlin_noise(p), accum);
+        weight *= 0.5f;
+        p = v3(p.x * 2.0f, p.y * 2.0f, p.z * 2.0f);
+    }
+    return fabsf(accum);
+}
+RTF_DEV V3 fast_tex_value(const DevScene &S, int idx, float u, float v, V3 p)
+{
+    rt_texture t = S.textures[idx];
+    for (int guard = 0; guard < 8 && t.kind == RT_TEX_CHECKER; ++guard) { // src/texture.h:26-37
+        const float sines = __sinf(10.0f * p.x) * __sinf(10.0f * p.y) * __sinf(10.0f * p.z);
+        t = S.textures[sines < 0.0f ? t.a : t.b];
+    }
+    if (t.kind == RT_TEX_CONSTANT) return v3(t.color[0], t.color[1], t.color[2]);
+    if (t.kind == RT_TEX_NOISE) { // src/texture.h:47-53
+        const float c = 0.5f * (1.0f + __sinf(fmaf(10.0f, fast_perlin_turb(v3(t.scale * p.x, t.scale * p.y, t.scale * p.z)), t.scale * p.z)));
+        return v3(c, c, c);
+    }
+    if (t.kind == RT_TEX_IMAGE) { // src/texture.h:63-77
+        int i = (int)(u * (float)t.nx);
+        int j = (int)((1.0f - v) * (float)t.ny - 0.001f);
+        i = i < 0 ? 0 : i, j = j < 0 ? 0 : j;
+        i = i > t.nx - 1 ? t.nx - 1 : i, j = j > t.ny - 1 ? t.ny - 1 : j;
+        const uint8_t *d = S.texels + t.offset + 3 * i + 3 * t.nx * j;
+        return v3((float)d[0] * (1.0f / 255.0f), (float)d[1] * (1.0f / 255.0f), (float)d[2] * (1.0f / 255.0f));
+    }
+    return v3(0, 0, 0); // a checker nested deeper than 8 levels
+}
+
 // lambertian::scatter + the mixture pdf of color() (src/material.h:35-50, src/main.cpp:104-121), after the coin
 // (`to_light`) and, for a lane that samples the important list, the member (`lp`) have been drawn.
 // mixture_pdf::generate (src/pdf.h:71-79): half the lanes sample the important list, half the cosine lobe.  A sphere
@@ -536,7 +592,7 @@ RTF_DEV bool shade(const DevScene &S, const uint32_t *__restrict__ recs, const L
     const bool is_light = h.mat_kind == RT_MAT_DIFFUSE_LIGHT;
     const int fate = !hit_any ? END : is_light ? LIGHT : !(depth < max_depth) ? END : h.mat_kind == RT_MAT_LAMBERTIAN ? DIFFUSE : SPECULAR;
     V3 albedo = h.color;
-    if (TEX && hit_any && h.texture >= 0) albedo = rt::tex_value(S, h.texture, h.u, h.v, h.p);
+    if (TEX && hit_any && h.texture >= 0) albedo = fast_tex_value(S, h.texture, h.u, h.v, h.p);
     L = fate == LIGHT ? v3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z) : v3(0, 0, 0);
     bool go = fate >= DIFFUSE;
     V3 nd = r.d, mul = albedo;
