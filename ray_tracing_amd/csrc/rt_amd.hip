@@ -1003,7 +1003,7 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     // the record-table path has two kernels: one wave per 8x8 tile (render_fast_kernel), or one block of four waves per
     // 16x16 tile that regroups its paths by class between scan and shade (render_fast_block_kernel: no textures, depth
     // and light list small enough for its packed state word)
-    static const bool block_off = getenv("RT_AMD_NO_BLOCK_KERNEL") != nullptr; // tuning aid
+    const bool block_off = getenv("RT_AMD_NO_BLOCK_KERNEL") != nullptr; // tuning / test aid: the wave kernel instead
     const bool block_kernel = use_fast && s->fast_ok && !s->fast_textured && !block_off && p->max_depth < 65536 && s->layout.n_lights <= 16;
     const int tile_w = block_kernel ? 4 * BLOCK_WAVES : 8, tile_h = block_kernel ? 16 : 8, waves_per_task = block_kernel ? BLOCK_WAVES : 1;
     RenderArgs A;

@@ -140,6 +140,21 @@ def test_render_matches_oracle_on_the_same_stream(nx, ny, ns, nss, depth, path):
     sc.close()
 
 
+def test_block_kernel_and_wave_kernel_trace_the_same_paths(cornell_gpu, monkeypatch):
+    """The record-table path has two kernels (one wave per 8x8 tile; one block per 16x16 tile that regroups its paths by
+    class).  Paths are keyed by (pixel, sample) and both kernels run the same per-path code, so their images agree up to
+    float summation order."""
+    nx, ny, ns = 80, 48, 8
+    block = gpu_render(cornell_gpu, nx, ny, 0, ns, sub_samples=2, max_depth=50, seed=6)
+    monkeypatch.setenv("RT_AMD_NO_BLOCK_KERNEL", "1")
+    wave = gpu_render(cornell_gpu, nx, ny, 0, ns, sub_samples=2, max_depth=50, seed=6)
+    monkeypatch.delenv("RT_AMD_NO_BLOCK_KERNEL")
+    assert np.all(block[..., 0] == ns) and np.all(wave[..., 0] == ns)
+    close = np.isclose(block[..., 1:], wave[..., 1:], rtol=1e-4, atol=1e-5).all(axis=-1)
+    assert close.mean() >= 0.995, f"only {close.mean():.4f} of pixels agree"
+    assert np.allclose(block[..., 1:].mean(axis=(0, 1)), wave[..., 1:].mean(axis=(0, 1)), rtol=1e-3)
+
+
 def test_generic_scan_with_box_records_matches_oracle(monkeypatch):
     """Scenes of more than 16 primitives keep their box records in the record table and are scanned by the generic loop
     (lanes that miss a box skip its subtree).  No built-in scene of that size fits the table, so the Cornell box is built
