@@ -523,13 +523,7 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
                 const float f0 = rtf::sh_f(R.d[0], hit_rec), f1 = rtf::sh_f(R.d[1], hit_rec), f2 = rtf::sh_f(R.d[2], hit_rec);
                 const float f4 = rtf::sh_f(R.d[4], hit_rec), f5 = rtf::sh_f(R.d[5], hit_rec), f6 = rtf::sh_f(R.d[6], hit_rec);
                 sf.p = p, sf.u = sf.v = 0.0f;
-                if ((kw2 & 15u) == RT_REC_SPHERE) {
-                    const float k = (kw2 & RT_KW_FLIP) ? -f4 : f4;
-                    sf.n = v3((p.x - f0) * k, (p.y - f1) * k, (p.z - f2) * k);
-                } else {
-                    const bool xz = ((kw2 >> RT_KW_AXIS_SHIFT) & 3u) == 1u;
-                    sf.n = v3(f5, xz ? ((kw2 & RT_KW_FLIP) ? -1.0f : 1.0f) : 0.0f, f6);
-                }
+                sf.n = rtf::record_normal(R, kw2, hit_rec, p, f0, f1, f2, f4, f5, f6, sf.face);
                 const int m2 = Y.materials_base + (int)((kw2 >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK);
                 sf.mat_kind = rtf::sh_u(R.d[0], m2);
                 sf.texture = -1;
@@ -589,7 +583,8 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
     if (!alive) return;
     const bool any = rec >= 0;
     rt_hit o;
-    o.prim_id = any ? rec_user[rec] : -1;
+    // (a box record names its face: the ids of the six rects follow the 64 record ids)
+    o.prim_id = any ? ((kw & 15u) == RT_REC_BOX ? rec_user[RT_REC_MAX + 6 * rec + sf.face] : rec_user[rec]) : -1;
     o.material = any ? (int)((kw >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK) : -1;
     o.t = any ? t : 0.0f, o.u = 0.0f, o.v = 0.0f;
     o.p[0] = any ? sf.p.x : 0.0f, o.p[1] = any ? sf.p.y : 0.0f, o.p[2] = any ? sf.p.z : 0.0f;
@@ -754,7 +749,7 @@ struct rt_scene {
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     const char *fast_why = "";
     rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0};
-    uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids (inside blob)
+    uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids and 64 x 6 face ids (inside blob)
     int32_t *d_rec_user = nullptr;
     int render_path = RT_PATH_AUTO, trace_path = RT_PATH_AUTO;
     int last_render_path = RT_PATH_EXACT;
@@ -896,7 +891,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         {d->texels, (size_t)d->n_texel_bytes, 0},
         {d->lights, sizeof(int32_t) * (size_t)d->n_lights, 0},
         {tab.rec, sizeof tab.rec, 0},
-        {tab.user_id, sizeof tab.user_id, 0},
+        {tab.user_id, sizeof tab.user_id + sizeof tab.face_user, 0}, // face_user follows user_id (asserted below)
         {order.data(), sizeof(int32_t) * order.size(), 0},
         {bvh.data(), sizeof(rt_bvh_node) * bvh.size(), 0},
         {fprims.data(), sizeof(rt_prim) * fprims.size(), 0},
@@ -952,6 +947,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     for (int m = 0; lanes_ok && m < d->n_materials; ++m)
         s->fast_textured |= d->materials[m].texture >= 0 && d->textures[d->materials[m].texture].kind != RT_TEX_CONSTANT;
     s->d_records = (uint32_t *)(b + parts[8].off);
+    static_assert(offsetof(rt_record_table, face_user) == offsetof(rt_record_table, user_id) + sizeof tab.user_id, "one upload");
     s->d_rec_user = (int32_t *)(b + parts[9].off);
     s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights, {tab.run[0], tab.run[1], tab.run[2], tab.run[3]}, tab.n_runs, tab.n_spheres};
     s->fast_flat = fast_ok && tab.flat != 0 && tab.n_runs > 0; // the run scan; else the generic one (it also walks flat streams)

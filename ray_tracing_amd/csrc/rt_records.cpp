@@ -46,6 +46,38 @@ void chain_up_normal(const rt_scene_desc *d, int chain, float n[3])
     }
 }
 
+// Is this list the reference's box (src/box.h:19-31)?  Six rects, two per axis, that span p0..p1, the one at p0 of each
+// pair with its normal flipped (outward normals), one material.  face[2*axis + side]: the member that is that face.
+bool as_box(const rt_scene_desc *d, const rt_prim &g, float lo[3], float hi[3], int face[6])
+{
+    if (g.kind != RT_PRIM_GROUP || g.count != 6) return false;
+    for (int k = 0; k < 6; ++k) face[k] = -1;
+    for (int k = 0; k < 6; ++k) {
+        const rt_prim &c = d->prims[g.first + k];
+        int axis; // the axis the rect is normal to
+        if (c.kind == RT_PRIM_YZ_RECT) axis = 0;
+        else if (c.kind == RT_PRIM_XZ_RECT) axis = 1;
+        else if (c.kind == RT_PRIM_XY_RECT) axis = 2;
+        else return false;
+        if (c.material != d->prims[g.first].material || (c.flags & RT_PRIM_NEEDS_UV)) return false;
+        const int slot = 2 * axis + ((c.flags & RT_PRIM_FLIP) ? 0 : 1);
+        if (face[slot] >= 0) return false;
+        face[slot] = g.first + k;
+    }
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = d->prims[face[2 * a]].f[4], hi[a] = d->prims[face[2 * a + 1]].f[4];
+        if (!(lo[a] < hi[a])) return false;
+    }
+    // a yz rect spans (y, z), an xz rect (x, z), an xy rect (x, y): src/plane.h
+    static const int A[3] = {1, 0, 0}, B[3] = {2, 2, 1};
+    for (int k = 0; k < 6; ++k) {
+        const float *f = d->prims[face[k]].f;
+        const int a = k / 2;
+        if (f[0] != lo[A[a]] || f[1] != hi[A[a]] || f[2] != lo[B[a]] || f[3] != hi[B[a]]) return false;
+    }
+    return true;
+}
+
 // the light records (important_hitables), from record `at` on; returns the index after them
 int emit_lights(const rt_scene_desc *d, rt_record_table *out, int at)
 {
@@ -76,6 +108,9 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
     *why = ok;
     memset(out, 0, sizeof *out);
     for (int i = 0; i < RT_REC_MAX; ++i) out->user_id[i] = out->prim[i] = -1;
+    memset(out->face_user, 0xff, sizeof out->face_user);
+    float box_lo[3], box_hi[3];
+    int box_face[6];
 
     // ---- does the scene qualify, and how many records does it need? ----------------
     std::vector<int> map(d->n_entries + 1, 0); // entry index -> stream index
@@ -95,7 +130,7 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
     for (int e = 0; e < d->n_entries; ++e)
         if ((d->entries[e].b & 255) == RT_ENTRY_LEAF) {
             const rt_prim &p = d->prims[d->entries[e].a];
-            n_leaf_records += p.kind == RT_PRIM_GROUP ? p.count : 1;
+            n_leaf_records += p.kind == RT_PRIM_GROUP && !as_box(d, p, box_lo, box_hi, box_face) ? p.count : 1;
         }
     // (RT_AMD_RECORDS_KEEP_BOXES: test aid -- small scenes keep their box records too, so the tests reach the generic scan)
     const bool keep_inner = n_leaf_records > RT_REC_FLAT_LEAVES || getenv("RT_AMD_RECORDS_KEEP_BOXES") != nullptr;
@@ -109,7 +144,10 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             continue;
         }
         const rt_prim &p = d->prims[en.a];
-        if (p.kind == RT_PRIM_GROUP) {
+        if (as_box(d, p, box_lo, box_hi, box_face)) { // one slab test instead of six rect tests
+            use_chain(p.chain);
+            n_stream += 2;
+        } else if (p.kind == RT_PRIM_GROUP) {
             for (int k = 0; k < p.count; ++k) {
                 const rt_prim &c = d->prims[p.first + k];
                 if (!plain_static(c.kind)) { *why = "a list member is not a static sphere or rect"; return 0; }
@@ -216,7 +254,23 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             continue;
         }
         const rt_prim &p = d->prims[en.a];
-        if (p.kind == RT_PRIM_GROUP) {
+        if (as_box(d, p, box_lo, box_hi, box_face)) {
+            // The nearest of the six faces inside (t_min, best] is where the ray enters the slabs' intersection, or where
+            // it leaves it when the entry lies before t_min: the scan does that one test (rt_fast.hpp) and the face is
+            // named afterwards from the hit point, with what the second record holds.
+            uint32_t *r = out->rec[s], *x = out->rec[s + 1];
+            float c[3], ux[3] = {1.0f, 0.0f, 0.0f};
+            for (int k = 0; k < 3; ++k) r[k] = fbits(box_lo[k]), r[4 + k] = fbits(box_hi[k]), c[k] = 0.5f * (box_lo[k] + box_hi[k]);
+            chain_up_point(d, p.chain, c);
+            chain_up_normal(d, p.chain, ux);
+            for (int k = 0; k < 3; ++k) x[k] = fbits(c[k]);
+            x[3] = fbits(ux[0]), x[4] = fbits(ux[2]);
+            const uint32_t common = (3u << RT_KW_AXIS_SHIFT) | chain_word(p.chain) | RT_KW_FIRST | RT_KW_LAST;
+            r[7] = RT_REC_BOX | common | ((uint32_t)d->prims[p.first].material << RT_KW_MAT_SHIFT);
+            x[7] = RT_REC_BOX_AUX | common;
+            out->prim[s] = en.a;
+            for (int k = 0; k < 6; ++k) out->face_user[s][k] = d->prims[box_face[k]].user_id;
+        } else if (p.kind == RT_PRIM_GROUP) {
             // hitable_list::hit (src/hitable_list.h:18-34) keeps the nearest member, the later one on a tie, and
             // bvh_node::hit lets that result replace the best so far unless the best is strictly nearer
             // (src/bvh.h:132-139).  Letting every member compete with the best so far under the same rule
@@ -228,8 +282,9 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             emit_prim(s, en.a, p, p.chain, RT_KW_FIRST | RT_KW_LAST);
         }
     }
-    // A flat stream is stored in runs: chain by chain (world space first), within a chain the rects by axis, and all
-    // spheres (world space) at the end.  The scan (rt_fast.hpp) then runs one tight loop per run, with nothing to decode
+    // A flat stream is stored in runs: chain by chain (world space first), within a chain the rects by axis and then
+    // the boxes (each with its second record: the stable sort keeps the pair together), and all spheres (world space) at
+    // the end.  The scan (rt_fast.hpp) then runs one tight loop per run, with nothing to decode
     // per record; the run lengths travel in the kernel arguments.  (More than RT_REC_MAX_RUNS chains: n_runs = 0 and the
     // generic scan, which decodes every record, is used.)
     // The order of a flat stream only decides which of two hits at the SAME distance is kept.
@@ -247,10 +302,11 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             memcpy(out->rec[i], tmp.rec[order[i]], sizeof out->rec[i]);
             out->user_id[i] = tmp.user_id[order[i]];
             out->prim[i] = tmp.prim[order[i]];
+            memcpy(out->face_user[i], tmp.face_user[order[i]], sizeof out->face_user[i]);
         }
         int n_runs = 0;
         bool fits = true;
-        uint32_t counts[RT_REC_MAX_RUNS][3] = {};
+        uint32_t counts[RT_REC_MAX_RUNS][4] = {}; // xy, xz, yz rects; box records (two per box)
         uint32_t chains[RT_REC_MAX_RUNS] = {};
         for (int i = 0; i < n_stream; ++i) {
             uint32_t *r = out->rec[i];
@@ -263,12 +319,12 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
                 if (n_runs == RT_REC_MAX_RUNS) { fits = false; continue; }
                 chains[n_runs++] = chain_of(r);
             }
-            if (fits && ++counts[n_runs - 1][(r[7] >> RT_KW_AXIS_SHIFT) & 3u] > 31u) fits = false;
+            if (fits && ++counts[n_runs - 1][(r[7] >> RT_KW_AXIS_SHIFT) & 3u] > 30u) fits = false;
         }
         out->n_runs = fits ? n_runs : 0;
         if (fits && n_runs == 0 && out->n_spheres > 0) out->n_runs = 1; // spheres only: one empty run in world space
         for (int k = 0; k < RT_REC_MAX_RUNS; ++k)
-            out->run[k] = fits ? (chains[k] << 15) | (counts[k][0] << 10) | (counts[k][1] << 5) | counts[k][2] : 0u;
+            out->run[k] = fits ? ((counts[k][3] / 2) << 24) | (chains[k] << 15) | (counts[k][0] << 10) | (counts[k][1] << 5) | counts[k][2] : 0u;
     }
     return 1;
 }

@@ -11,12 +11,15 @@
 //   RECT      d0 a0, d1 a1, d2 b0, d3 b1, d4 k, d5 world normal x, d6 world normal z
 //             (world normal y is +-1 for an xz rect and 0 otherwise: chains are y-rotations and shifts)
 //   SPHERE    d0-2 centre IN WORLD SPACE (a rigid chain is folded in), d3 radius, d4 1/radius
+//   BOX       d0-2 p0, d4-6 p1 in the space of its chain (src/box.h: six rects, here ONE slab test); always followed by
+//   BOX_AUX   d0-2 the box centre IN WORLD SPACE, d3/d4 x and z of the world image of the box's x axis (the image of
+//             its z axis is (-d4, 0, d3): chains are y-rotations and shifts); read after the scan to name the face
 //   XFORM_T   d0-2 offset                     (src/transforms.h:14-28)
 //   XFORM_R   d0 sin_theta, d1 cos_theta      (src/transforms.h:102-130)
 //   MATERIAL  d0 (int) rt_material_kind, d1 (int) texture index or -1 when the colour is inline,
 //             d2 p0 (fuzz / ref_idx), d3-5 constant colour
 //   LIGHT     d0-4 as RECT (xz) or d0-3 as SPHERE, d5 rect area
-// kind word:  bits 0-3 kind | 4-5 rect axis (0 xy, 1 xz, 2 yz) | 6 flip | 7 first of its list | 8 last of its list
+// kind word:  bits 0-3 kind | 4-5 rect axis (0 xy, 1 xz, 2 yz; 3 for BOX and BOX_AUX) | 6 flip | 7 first of its list | 8 last of its list
 //             | 9-14 first record of the instance chain | 15-17 number of chain records
 //             | 18-25 material record (relative to materials_base)
 #ifndef RT_RECORDS_H_
@@ -38,7 +41,9 @@ enum rt_rec_kind {
     RT_REC_MATERIAL = 5,
     RT_REC_LIGHT_RECT = 6,
     RT_REC_LIGHT_SPHERE = 7,
-    RT_REC_LIGHT_NONE = 8
+    RT_REC_LIGHT_NONE = 8,
+    RT_REC_BOX = 9,
+    RT_REC_BOX_AUX = 10
 };
 
 #define RT_KW_AXIS_SHIFT 4
@@ -53,15 +58,17 @@ enum rt_rec_kind {
 typedef struct rt_record_table {
     uint32_t rec[RT_REC_MAX + 1][8]; /* one spare record: the scan prefetches record i+1 */
     int32_t user_id[RT_REC_MAX]; /* rt_prim.user_id of primitive records (for rt_trace_rays) */
-    int32_t prim[RT_REC_MAX];    /* rt_prim index of primitive records */
+    int32_t face_user[RT_REC_MAX][6]; /* BOX records: user_id of the face rects, [2*axis + side] (axis x,y,z; side 0 at p0, 1 at p1) */
+    int32_t prim[RT_REC_MAX];    /* rt_prim index of primitive records (BOX: the list) */
     int32_t n_stream;            /* records [0, n_stream) are the traversal stream */
     int32_t materials_base;
     int32_t lights_base, n_lights;
     int32_t n_records;
     int32_t flat;                /* 1: the stream holds no inner (box) records */
-    /* flat streams are stored in RUNS: for each instance chain (world space first) its rects by axis (xy, xz, yz), then
-     * all spheres (world space).  run[r] = chain word << 15 | n_xy << 10 | n_xz << 5 | n_yz.  n_runs == 0: the stream
-     * has more than RT_REC_MAX_RUNS chains (or a run above 31 records); the generic scan then decodes every record. */
+    /* flat streams are stored in RUNS: for each instance chain (world space first) its rects by axis (xy, xz, yz) and its
+     * boxes (two records each), then all spheres (world space).
+     * run[r] = n_box << 24 | chain word << 15 | n_xy << 10 | n_xz << 5 | n_yz.  n_runs == 0: the stream has more than
+     * RT_REC_MAX_RUNS chains (or a run above 31 rects of an axis / 15 boxes); the generic scan then decodes every record. */
     uint32_t run[4];
     int32_t n_runs, n_spheres;
 } rt_record_table;
