@@ -471,9 +471,7 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
                     to_light = rng.next() < 0.5f ? 1 : 0;
                     if (to_light) {
                         light = rtf::lights_index(Y, rng);
-                        uint32_t lk = RT_REC_LIGHT_NONE; // kind of the member this lane drew (wave-uniform loads)
-                        for (int k = 0; k < Y.n_lights; ++k) lk = light == k ? (recs[8 * (Y.lights_base + k) + 7] & 15u) : lk;
-                        cls = lk == RT_REC_LIGHT_RECT ? 1 : 2;
+                        cls = ((Y.rect_lights >> light) & 1u) ? 1 : 2; // a rect needs no basis; a sphere (or nothing) joins the cap lanes
                     }
                 }
             }
@@ -536,7 +534,7 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
             if (alive & (cls == 0)) rtf::scatter_specular(sf, d, rng, nd, mul, ntime);
             if (alive & (cls != 0)) {
                 rtf::LightPick lp{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                if (to_light) lp = rtf::light_of_index(recs, Y, light);
+                if (to_light) lp = rtf::light_of_index_lds(lrecs, Y, light);
                 rtf::scatter_lambert(recs, Y, sf, sf.color, to_light != 0, lp, rng, nd, mul, go);
             }
             d = nd, time = ntime;
@@ -949,7 +947,9 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     s->d_records = (uint32_t *)(b + parts[8].off);
     static_assert(offsetof(rt_record_table, face_user) == offsetof(rt_record_table, user_id) + sizeof tab.user_id, "one upload");
     s->d_rec_user = (int32_t *)(b + parts[9].off);
-    s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights, {tab.run[0], tab.run[1], tab.run[2], tab.run[3]}, tab.n_runs, tab.n_spheres};
+    s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights, {tab.run[0], tab.run[1], tab.run[2], tab.run[3]}, tab.n_runs, tab.n_spheres, 0u};
+    for (int k = 0; k < tab.n_lights && k < 32; ++k)
+        if ((tab.rec[tab.lights_base + k][7] & 15u) == RT_REC_LIGHT_RECT) s->layout.rect_lights |= 1u << k;
     s->fast_flat = fast_ok && tab.flat != 0 && tab.n_runs > 0; // the run scan; else the generic one (it also walks flat streams)
     *out = s;
     return RT_OK;

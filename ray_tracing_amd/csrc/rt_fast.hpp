@@ -70,6 +70,7 @@ struct Layout { // wave-uniform description of the table
     int32_t n_stream, materials_base, lights_base, n_lights;
     uint32_t run[RT_REC_MAX_RUNS]; // rt_records.h: the runs of a flat stream
     int32_t n_runs, n_spheres;
+    uint32_t rect_lights; // bit k: member k of the important list is a rect (the first 32 members)
 };
 
 // the ray in the space of the current chain, with what the slab and rect tests need
@@ -428,11 +429,15 @@ RTF_DEV V3 rnd_unit_disk(Rng &rng) // src/utils.h:44-55
 }
 struct Onb {
     V3 u, v, w;
-    RTF_DEV void build_from_w(V3 n) // src/vec3.h:209-224
+    // src/vec3.h:209-224 with the cross products against (0,1,0) / (1,0,0) written out:
+    // w x (0,1,0) = (-w.z, 0, w.x) and w x (1,0,0) = (0, w.z, -w.y)
+    RTF_DEV void build_from_w(V3 n)
     {
         w = funit(n);
-        const V3 a = fabsf(w.x) > 0.9f ? v3(0, 1, 0) : v3(1, 0, 0);
-        v = funit(fcross(w, a));
+        const bool big = fabsf(w.x) > 0.9f;
+        const float other = big ? w.x : w.y;
+        const float k = rsq(fmaf(other, other, w.z * w.z));
+        v = v3(big ? -w.z * k : 0.0f, big ? 0.0f : w.z * k, (big ? w.x : -w.y) * k);
         u = fcross(w, v);
     }
     RTF_DEV V3 local(V3 a) const
@@ -442,11 +447,12 @@ struct Onb {
     }
 };
 
-// hitable_list::pdf_value over the light records, src/hitable_list.h:67-77
+// hitable_list::pdf_value over the light records, src/hitable_list.h:67-77, for a direction of UNIT length (the only
+// caller has just normalised it: dot(v,v), its root and its reciprocal drop out of the reference's formulas)
+RTF_DEV bool within(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi) == x; } // lo <= x <= hi, false for NaN
 RTF_DEV float lights_pdf_value(const uint32_t *__restrict__ recs, const Layout &Y, V3 o, V3 v)
 {
     const float weight = rcp((float)Y.n_lights);
-    const float vv = fdot(v, v);
     float sum = 0.0f;
     for (int k = 0; k < Y.n_lights; ++k) {
         const SRec c = load_rec(recs, Y.lights_base + k);
@@ -455,18 +461,14 @@ RTF_DEV float lights_pdf_value(const uint32_t *__restrict__ recs, const Layout &
         if (kind == RT_REC_LIGHT_RECT) { // xz_rect::pdf_value, src/plane.h:76-91
             const float t = (sf(c, 4) - o.y) * rcp(v.y);
             const float x = fmaf(t, v.x, o.x), z = fmaf(t, v.z, o.z);
-            const bool in = (t >= 0.0001f) & (x >= sf(c, 0)) & (x <= sf(c, 1)) & (z >= sf(c, 2)) & (z <= sf(c, 3));
-            const float cosine = fabsf(v.y) * rsq(vv);
-            pdf = in ? t * t * vv * rcp(cosine * sf(c, 5)) : 0.0f;
+            const bool in = (t >= 0.0001f) & within(x, sf(c, 0), sf(c, 1)) & within(z, sf(c, 2), sf(c, 3));
+            pdf = in ? t * t * rcp(fabsf(v.y) * sf(c, 5)) : 0.0f;
         } else if (kind == RT_REC_LIGHT_SPHERE) { // sphere::pdf_value, src/sphere.h:68-83
             const V3 oc = v3(o.x - sf(c, 0), o.y - sf(c, 1), o.z - sf(c, 2));
             const float radius = sf(c, 3);
             const float b = fdot(oc, v), occ = fdot(oc, oc);
-            const float cc = fmaf(-radius, radius, occ);
-            const float disc = fmaf(b, b, -(vv * cc));
-            const float sq = fsqrt(disc), ia = rcp(vv);
-            const float t1 = (-b - sq) * ia, t2 = (-b + sq) * ia;
-            const bool in = (disc > 0.0f) & ((t1 > 0.001f) | (t2 > 0.001f));
+            const float disc = fmaf(b, b, fmaf(radius, radius, -occ));
+            const bool in = (disc > 0.0f) & (fsqrt(disc) - b > 0.001f); // the larger root decides (t1 <= t2)
             const float cos_theta_max = fsqrt(1.0f - radius * radius * rcp(occ));
             pdf = in ? rcp(2.0f * RT_PI * (1.0f - cos_theta_max)) : 0.0f;
         }
@@ -499,6 +501,13 @@ RTF_DEV LightPick light_of_index(const uint32_t *__restrict__ recs, const Layout
         p.f3 = mine ? sf(c, 3) : p.f3, p.f4 = mine ? sf(c, 4) : p.f4;
     }
     return p;
+}
+// the same from the block's copy of the table in LDS: every lane reads the record it drew
+RTF_DEV LightPick light_of_index_lds(const uint32_t *lrecs, const Layout &Y, int index)
+{
+    const uint32_t *r = lrecs + 8 * (Y.lights_base + index);
+    const uint4 a = *reinterpret_cast<const uint4 *>(r);
+    return LightPick{r[7] & 15u, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(r[4])};
 }
 RTF_DEV LightPick lights_pick(const uint32_t *__restrict__ recs, const Layout &Y, Rng &rng)
 {
@@ -571,7 +580,7 @@ RTF_DEV V3 fast_tex_value(const DevScene &S, int idx, float u, float v, V3 p)
 RTF_DEV void scatter_lambert(const uint32_t *__restrict__ recs, const Layout &Y, const Surface &h, V3 albedo, bool to_light,
                              const LightPick &lp, Rng &rng, V3 &nd, V3 &mul, bool &go)
 {
-    const V3 wn = funit(h.n);
+    const V3 wn = h.n; // of unit length: rect and box normals by construction, a sphere's (p - c) / r to rounding
     V3 dir = v3(1, 0, 0); // hitable::random, src/hitable.h:20
     if (to_light & (lp.kind == RT_REC_LIGHT_RECT)) {
         const float rz = rng.next(), rx = rng.next();
@@ -597,10 +606,10 @@ RTF_DEV void scatter_lambert(const uint32_t *__restrict__ recs, const Layout &Y,
         dir = uvw.local(v3(c * q, s * q, z));
     }
     dir = funit(dir);
-    const float cosine = fdot(dir, wn);
-    const float cos_val = cosine > 0.0f ? cosine * (1.0f / RT_PI) : 0.0f;
-    const float pdf_val = 0.5f * lights_pdf_value(recs, Y, h.p, dir) + 0.5f * cos_val;
-    const float sc = fmaxf(fdot(h.n, dir), 0.0f) * (1.0f / RT_PI);
+    // cosine_pdf::value (src/pdf.h:23-30) and lambertian::scattering_pdf (src/material.h:35-41) are the same number
+    // once the normal has unit length: max(0, cos) / pi
+    const float sc = fmaxf(fdot(wn, dir), 0.0f) * (1.0f / RT_PI);
+    const float pdf_val = 0.5f * lights_pdf_value(recs, Y, h.p, dir) + 0.5f * sc;
     const float wgt = sc * rcp(pdf_val);
     nd = dir;
     mul = v3(albedo.x * wgt, albedo.y * wgt, albedo.z * wgt);
