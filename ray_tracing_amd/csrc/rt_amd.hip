@@ -444,6 +444,14 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
         float t = 0.0f;
         int rec = -1;
         if (__any(alive)) rtf::scan<FLAT>(recs, lrecs, Y, Ray{o, d, time}, 0.001f, RT_FLT_MAX, alive, t, rec);
+#ifdef RT_MEASURE_SCAN_TWICE // development (tools/build_variant.sh): the same scan again, to price the scan by difference
+        if (__any(alive)) {
+            float t2;
+            int rec2;
+            rtf::scan<FLAT>(recs, lrecs, Y, Ray{o, d, time}, 0.0010001f, RT_FLT_MAX, alive, t2, rec2);
+            if (t2 < t) t = t2, rec = rec2;
+        }
+#endif
 
         // ---- what needs no company: the path ends (miss, lamp, depth limit) or gets its class -----------------------------
         const int src = rec < 0 ? 0 : rec;
@@ -531,6 +539,20 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
             V3 nd = d, mul = sf.color;
             float ntime = time;
             bool go = alive;
+#ifdef RT_MEASURE_SHADE_TWICE // development: the scatter once more on another stream, its result kept at zero weight
+            {
+                Rng rng2{rng.x ^ 0x5bd1e995u};
+                V3 nd2 = d, mul2 = sf.color;
+                bool go2 = alive;
+                if (alive & (cls == 0)) rtf::scatter_specular(sf, d, rng2, nd2, mul2, ntime);
+                if (alive & (cls != 0)) {
+                    rtf::LightPick lp{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    if (to_light) lp = rtf::light_of_index_lds(lrecs, Y, light);
+                    rtf::scatter_lambert(recs, Y, sf, sf.color, to_light != 0, lp, rng2, nd2, mul2, go2);
+                }
+                T.x += (go2 ? nd2.x + mul2.y : 1.0f) * 1e-37f;
+            }
+#endif
             if (alive & (cls == 0)) rtf::scatter_specular(sf, d, rng, nd, mul, ntime);
             if (alive & (cls != 0)) {
                 rtf::LightPick lp{RT_REC_LIGHT_NONE, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};

@@ -252,8 +252,11 @@ RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs,
         rect_run(lrecs, index, (int)(w & 31u), t_min, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best_t, best_rec);
         box_run(lrecs, index, (int)(w >> 24), t_min, l, best_t, best_rec);
     }
+    // spheres, world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree.  The smaller root is
+    // the hit if it lies behind t_min, else only the larger one can be; best_t <= t_max, and a negative discriminant
+    // makes every comparison false, so the update is three narrowing comparisons (as in rect_update_v).
     const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
-    for (int k = 0; k < Y.n_spheres; ++k, ++index) { // world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree
+    for (int k = 0; k < Y.n_spheres; ++k, ++index) {
         const LRec c = lds_rec(lrecs, index);
         const V3 oc = v3(wr.o.x - __uint_as_float(c.a.x), wr.o.y - __uint_as_float(c.a.y), wr.o.z - __uint_as_float(c.a.z));
         const float radius = __uint_as_float(c.a.w);
@@ -261,12 +264,21 @@ RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs,
         const float cc = fmaf(-radius, radius, fdot(oc, oc));
         const float disc = fmaf(b, b, -(w_dd * cc));
         const float sq = fsqrt(disc);
-        const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
-        const bool in1 = (t1 < t_max) & (t1 > t_min), in2 = (t2 < t_max) & (t2 > t_min);
-        const float t = in1 ? t1 : t2;
-        const bool in = (disc > 0.0f) & (in1 | in2) & (t <= best_t);
-        best_t = in ? t : best_t;
-        best_rec = in ? index : best_rec;
+        const float t1 = (-b - sq) * w_inv_dd, t2 = (sq - b) * w_inv_dd;
+        float t;
+        unsigned long long saved;
+        asm volatile("v_cmp_lt_f32 vcc, %[tmin], %[t1]\n\t"
+                     "v_cndmask_b32 %[t], %[t2], %[t1], vcc\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_f32 0, %[disc]\n\t"
+                     "v_cmpx_lt_f32 %[tmin], %[t]\n\t"
+                     "v_cmpx_ge_f32 %[bt], %[t]\n\t"
+                     "v_mov_b32 %[bt], %[t]\n\t"
+                     "v_mov_b32 %[br], %[idx]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [t] "=&v"(t), [sv] "=&s"(saved), [bt] "+v"(best_t), [br] "+v"(best_rec)
+                     : [t1] "v"(t1), [t2] "v"(t2), [disc] "v"(disc), [tmin] "s"(t_min), [idx] "s"(index)
+                     : "vcc");
     }
     best_rec = alive ? best_rec : -1;
 }
