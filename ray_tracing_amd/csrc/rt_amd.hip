@@ -405,6 +405,7 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
     float time = 0.0f;
     Rng rng{0u};
     int depth = 0, pix = tid;
+    int turn = 0;
 
     for (;;) {
         // ---- refill: dead lanes (together in the last waves after the regroup) take items from the block's pool --------
@@ -509,7 +510,12 @@ __global__ __launch_bounds__(64 * NW) void render_fast_block_kernel(DevScene S, 
         xch[2][dst] = make_uint4(__float_as_uint(T.z), rng.x, packed, (uint32_t)src);
         __syncthreads();
         if (n_dead == NT && pool_now >= total) break; // the same for every wave of the block
-        const uint4 q0 = xch[0][tid], q1 = xch[1][tid], q2 = xch[2][tid];
+        // The slots are sorted by class, so read in place wave 0 would always get the costliest paths and the last wave the
+        // waiting lanes -- and a block's waves sit on different SIMDs.  The block therefore reads the slots rotated by one
+        // wave more every round: each SIMD sees every class in turn.
+        const int slot = (tid + turn) & (NT - 1);
+        turn += 64;
+        const uint4 q0 = xch[0][slot], q1 = xch[1][slot], q2 = xch[2][slot];
         p = v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
         d = v3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
         T = v3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
