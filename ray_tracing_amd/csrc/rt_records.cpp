@@ -297,7 +297,30 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             return (chain_of(r) << 2) | ((r[7] >> RT_KW_AXIS_SHIFT) & 3u);
         };
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(out->rec[a]) < key(out->rec[b]); });
+        // The reference's tree holds the only object of a one-object node twice (left == right, src/bvh.h:92-94), and so does
+        // the entry array.  Without media a second test of the same primitive changes nothing: it is dropped here.
+        {
+            std::vector<int> kept;
+            std::vector<char> seen(d->n_prims, 0);
+            for (int i : order) {
+                const bool aux = (out->rec[i][7] & 15u) == RT_REC_BOX_AUX;
+                const int prim = aux ? out->prim[i - 1] : out->prim[i];
+                if (!aux && seen[prim]) continue;
+                if (aux && seen[prim] == 2) continue;
+                if (!aux) seen[prim] = 1;
+                else seen[prim] = 2; // the second half of a box goes with its first occurrence only
+                kept.push_back(i);
+            }
+            order.swap(kept);
+        }
         rt_record_table tmp = *out;
+        for (int i = (int)order.size(); i < n_stream; ++i) {
+            memset(out->rec[i], 0, sizeof out->rec[i]);
+            out->user_id[i] = out->prim[i] = -1;
+            memset(out->face_user[i], 0xff, sizeof out->face_user[i]);
+        }
+        n_stream = (int)order.size();
+        out->n_stream = n_stream;
         for (int i = 0; i < n_stream; ++i) {
             memcpy(out->rec[i], tmp.rec[order[i]], sizeof out->rec[i]);
             out->user_id[i] = tmp.user_id[order[i]];

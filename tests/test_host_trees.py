@@ -1,5 +1,6 @@
-"""Host-side tree builders (no GPU): the library's SAH tree with half-float boxes (rt_bvh.cpp) and the side table of the
-ordered walk of the reference's tree (rt_order.cpp), checked by a small C++ program built here with g++."""
+"""Host-side builders (no GPU): the library's SAH tree with half-float boxes (rt_bvh.cpp), the side table of the ordered walk
+of the reference's tree (rt_order.cpp) and the record table of small scenes (rt_records.cpp), checked by small C++ programs
+built here with g++."""
 import os
 import subprocess
 
@@ -23,3 +24,25 @@ def test_trees_hold_every_primitive_inside_conservative_boxes(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "half rounding: 0 bad" in p.stdout and "failures: 0" in p.stdout
     assert p.stdout.count("ok=1") == len(SCENES)
+
+
+def test_record_tables_of_small_scenes(tmp_path):
+    """The Cornell box fits the record table: six wall/light rects, the rotated box as ONE record pair whose six faces keep
+    their own ids, the glass sphere last, two runs (world space; the box's chain).  Scenes with media or too many primitives
+    do not fit and say why."""
+    exe = str(tmp_path / "records_check")
+    if not os.path.exists(os.path.join(PKG, "librt_amd.so")):
+        subprocess.run(["make", "-C", PKG], check=True)
+    subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "cpp", "records_check.cpp"),
+                    "-L" + PKG, "-lrt_amd", "-Wl,-rpath," + PKG, "-o", exe], check=True)
+    p = subprocess.run([exe, "cornell_box", "two_perlin_spheres", "simple_scene", "cornell_box_volumes", "random_spheres"],
+                       capture_output=True, text=True, timeout=600)
+    print(p.stdout)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = {ln.split(":")[0]: ln for ln in p.stdout.splitlines() if ":" in ln}
+    assert "fits=1" in lines["cornell_box"] and "stream=9 " in lines["cornell_box"] and "flat=1 runs=2 rects=6 boxes=1 spheres=1 bad=0" in lines["cornell_box"]
+    assert "fits=1" in lines["two_perlin_spheres"] and "bad=0" in lines["two_perlin_spheres"]
+    assert "fits=0 (scene has a constant_medium or a moving_sphere)" in lines["cornell_box_volumes"]
+    assert "stream=3 " in lines["two_perlin_spheres"] and "spheres=3" in lines["two_perlin_spheres"]  # the tree's doubled leaf once
+    assert "fits=0" in lines["random_spheres"] and "fits=0 (a texture reads (u,v))" in lines["simple_scene"]
+    assert "failures: 0" in p.stdout
