@@ -249,8 +249,8 @@ int rt_trace_rays(rt_scene* scene, int32_t n, const float* h_rays, float t_min, 
  *                  - anything else (media, moving spheres, (u,v) textures, up to millions of primitives):
  *                    every lane walks the library's own surface-area-heuristic tree over the same
  *                    primitives (RT_INFO_RECORDS == -1).
- * RT_PATH_AUTO (default): rt_render uses FAST, except for scenes of at most 64 tree entries that do not
- * fit the record table (their wave-uniform exact walk is the faster one); rt_trace_rays uses EXACT.
+ * RT_PATH_AUTO (default): rt_render uses FAST whenever one of its two forms can run the scene (EXACT is left
+ * for what neither can: RT_INFO_FAST_PATH_AVAILABLE == 0); rt_trace_rays uses EXACT.
  * No counterpart in the reference (it has one CPU path). */
 enum rt_option { RT_OPT_RENDER_PATH = 1, RT_OPT_TRACE_PATH = 2 };
 enum rt_path { RT_PATH_AUTO = 0, RT_PATH_EXACT = 1, RT_PATH_FAST = 2 };

@@ -1013,9 +1013,9 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     hipStream_t stream = (hipStream_t)stream_;
     if (s->render_path == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
         return rt_fail(RT_ERR_UNSUPPORTED, "rt_render: the fast path was requested but cannot run this scene (%s; and no ordered walk)", s->fast_why);
-    // AUTO: the record table when the scene fits; the per-lane fast path for large trees; small scenes that do not fit
-    // the table (media, moving spheres) stay on the wave-uniform exact walk, which beats a per-lane walk of a tiny tree
-    const bool use_fast = s->render_path == RT_PATH_FAST || (s->render_path == RT_PATH_AUTO && (s->fast_ok || (s->lanes_ok && s->dev.n_entries > RT_UNIFORM_WALK_MAX)));
+    // AUTO: the record table when the scene fits, else the per-lane fast path when it can run the scene (measured 2-7x the
+    // exact walk also on trees of a dozen nodes: tools/path_bench.py); the exact path is what is left
+    const bool use_fast = s->render_path == RT_PATH_FAST || (s->render_path == RT_PATH_AUTO && (s->fast_ok || s->lanes_ok));
     RT_HIP(hipSetDevice(s->device));
     const size_t bytes = sizeof(float) * 4 * (size_t)p->nx * p->ny;
     const bool accumulate = (p->flags & RT_RENDER_ACCUMULATE) != 0;

@@ -407,7 +407,7 @@ def test_ext_scene_fast_trace_close_to_exact(scene):
 @pytest.mark.parametrize("scene,nx,ny,spp", [("cornell_box_volumes", 64, 64, 64), ("random_spheres", 96, 64, 64), ("next_week_final", 64, 64, 32), ("sphere_field_4k", 64, 64, 64),
                                                  ("simple_scene", 64, 64, 64), ("another_simple", 64, 64, 64), ("two_perlin_spheres", 64, 64, 64)])
 def test_ext_scene_fast_render_statistics(scene, nx, ny, spp):
-    """The per-lane fast path (what AUTO picks for trees above 64 entries).  Its image is an independent unbiased estimate of the same
+    """The per-lane fast path (what AUTO picks for scenes that do not fit the record table).  Its image is an independent unbiased estimate of the same
     integral as the exact path's: per-channel image means agree within 3 standard errors (estimated from 8 batches per path)."""
     sc = Scene(HostScene(scene, nx / ny), 0)
     means = {}
