@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 16
 #endif
-template <bool TEX>
+template <bool TEX, bool BOX>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                                                                                  rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
 {
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fastlanes_kernel(
         if (w.cur >= 0) rtf::walk_node(S, w, 0.001f, stack);
         const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
         if (__popcll(__ballot(at_leaf)) >= RT_LEAF_BATCH || !__any(w.cur >= 0)) {
-            if (at_leaf) rtf::walk_leaf(S, w, r, 0.001f, rng, stack);
+            if (at_leaf) rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
         }
     }
 
@@ -746,10 +746,11 @@ __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n,
     if (!alive) return;
     rtf::Surface sf;
     sf.p = sf.n = v3(0, 0, 0), sf.u = sf.v = 0.0f;
-    if (any) rtf::build_surface_lanes(S, r, t, prim, sf);
     rt_hit o;
-    o.prim_id = any ? S.fprims[prim].user_id : -1;
-    o.material = any ? S.fprims[prim].material : -1;
+    sf.face = prim;
+    if (any) rtf::build_surface_lanes(S, r, t, prim, sf);
+    o.prim_id = any ? S.fprims[sf.face].user_id : -1; // a box names the face rect that was hit
+    o.material = any ? S.fprims[sf.face].material : -1;
     o.t = any ? t : 0.0f, o.u = sf.u, o.v = sf.v;
     o.p[0] = sf.p.x, o.p[1] = sf.p.y, o.p[2] = sf.p.z;
     o.normal[0] = sf.n.x, o.normal[1] = sf.n.y, o.normal[2] = sf.n.z;
@@ -773,6 +774,7 @@ struct rt_scene {
     bool fast_textured = false; // some material's texture is not a constant
     bool fast_flat = false;     // the record stream holds no box records and is stored in runs
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
+    bool lanes_boxes = false;   // its tree holds box leaves or media bounded by boxes (rt_box.h)
     const char *fast_why = "";
     rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids and 64 x 6 face ids (inside blob)
@@ -970,6 +972,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     for (int m = 0; fast_ok && m < d->n_materials; ++m)
         s->fast_textured |= (int32_t)tab.rec[tab.materials_base + m][1] >= 0;
     s->lanes_ok = lanes_ok;
+    for (const rt_prim &fp : fprims) s->lanes_boxes |= (fp.flags & RT_PRIM_IS_BOX) != 0;
     for (int m = 0; lanes_ok && m < d->n_materials; ++m)
         s->fast_textured |= d->materials[m].texture >= 0 && d->textures[d->materials[m].texture].kind != RT_TEX_CONSTANT;
     s->d_records = (uint32_t *)(b + parts[8].off);
@@ -1064,10 +1067,14 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     RT_HIP(hipEventRecord(s->ev0, stream));
     if (use_fast && s->lanes_ok) {
         const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
-        if (s->fast_textured)
-            hipLaunchKernelGGL(render_fastlanes_kernel<true>, g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+        if (s->fast_textured && s->lanes_boxes)
+            hipLaunchKernelGGL((render_fastlanes_kernel<true, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+        else if (s->fast_textured)
+            hipLaunchKernelGGL((render_fastlanes_kernel<true, false>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+        else if (s->lanes_boxes)
+            hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
         else
-            hipLaunchKernelGGL(render_fastlanes_kernel<false>, g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
     } else if (use_fast && block_kernel) {
         if (s->fast_flat)
             hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);

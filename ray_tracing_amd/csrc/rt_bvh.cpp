@@ -1,6 +1,8 @@
 // rt_bvh.cpp -- binned-SAH BVH2 over the world-space boxes of a scene's primitives (rt_bvh.h).
 #include "rt_bvh.h"
 
+#include "rt_box.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -284,11 +286,25 @@ bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::
         }
         return true;
     };
+    // A list that is a box (rt_box.h) is ONE item and one slab test for the walk, also as the boundary of a
+    // constant_medium: the library's copy of the list gets p0 / p1 and its members in the order [2 * axis + side].
+    auto mark_box = [&](int32_t gi) -> bool {
+        float lo[3], hi[3];
+        int face[6];
+        if (!rt_as_box(d, d->prims[gi], lo, hi, face)) return false;
+        rt_prim &g = prims[gi];
+        if (g.flags & RT_PRIM_IS_BOX) return true;
+        g.flags |= RT_PRIM_IS_BOX;
+        for (int k = 0; k < 3; ++k) g.f[k] = lo[k], g.f[3 + k] = hi[k];
+        for (int k = 0; k < 6; ++k) prims[g.first + k] = d->prims[face[k]];
+        return true;
+    };
     for (int e = 0; e < d->n_entries; ++e) {
         if ((d->entries[e].b & 255) != RT_ENTRY_LEAF) continue;
         const int32_t pi = d->entries[e].a;
         const rt_prim &p = d->prims[pi];
-        if (p.kind == RT_PRIM_GROUP) {
+        if (p.kind == RT_PRIM_MEDIUM && d->prims[p.first].kind == RT_PRIM_GROUP) mark_box(p.first);
+        if (p.kind == RT_PRIM_GROUP && !mark_box(pi)) {
             for (int k = 0; k < p.count; ++k)
                 if (!add_item(p.first + k)) return false;
         } else if (!add_item(pi)) {
@@ -319,6 +335,7 @@ bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::
         lf.kind_chain = (uint32_t)p.kind | ((uint32_t)shape.chain << 8);
         lf.prim = pi;
         lf.visits = p.reserved;
+        if (p.kind == RT_PRIM_GROUP) memcpy(&lf.visits, &p.f[5], 4); // a box: p1.z in the last word (visits do not matter to a surface)
         leaves.push_back(lf);
         return ~(int32_t)(leaves.size() - 1);
     };

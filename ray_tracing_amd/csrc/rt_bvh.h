@@ -33,18 +33,20 @@ typedef struct rt_bvh_node {
 
 /* Leaf, 32 bytes, stored in the order the tree's leaves are met (neighbours in space are neighbours in memory):
  * what the intersection test reads, and the rt_prim the hit is built from afterwards.
- *   sphere: f = cx cy cz r    rect: f = a0 a1 b0 b1 k    moving sphere, constant_medium: the test reads prims[prim] */
+ *   sphere: f = cx cy cz r    rect: f = a0 a1 b0 b1 k    moving sphere, constant_medium: the test reads prims[prim]
+ *   box (a GROUP that rt_box.h recognises): f = p0.x p0.y p0.z p1.x p1.y and p1.z in the last word */
 typedef struct rt_leaf {
     float    f[5];
     uint32_t kind_chain; /* rt_prim_kind | instance chain << 8 (of the shape; 0 = world space) */
     int32_t  prim;       /* index into the primitive table returned by rt_bvh_build */
-    int32_t  visits;     /* times the reference's tree visits this primitive (rt_bvh.cpp) */
+    int32_t  visits;     /* times the reference's tree visits this primitive (rt_bvh.cpp); box: the bits of p1.z */
 } rt_leaf;
 
-/* Builds the tree over the primitives the entry array names (each once; the members of a list -- box faces -- are
- * items of their own, so a leaf is always one sphere, one rect or one constant_medium).  `prims` receives the
- * primitive table rt_leaf.prim indexes: a copy of d->prims in which spheres under a rigid instance chain are moved to
- * world space (chain 0; not those whose texture reads (u,v), which is defined in the sphere's own frame).
+/* Builds the tree over the primitives the entry array names (each once; a list that is a box is one item, the members of
+ * any other list are items of their own, so a leaf is one sphere, one rect, one box or one constant_medium).  `prims`
+ * receives the primitive table rt_leaf.prim indexes: a copy of d->prims in which spheres under a rigid instance chain
+ * are moved to world space (chain 0; not those whose texture reads (u,v), which is defined in the sphere's own frame)
+ * and boxes carry RT_PRIM_IS_BOX, their corners and their faces in canonical order (rt_box.h).
  * Returns false when it cannot (a depth bound it could not keep, non-finite boxes, more than 2^24 chains); the caller
  * then has no fast path for large scenes. */
 bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::vector<rt_leaf> &leaves, std::vector<rt_prim> &prims,

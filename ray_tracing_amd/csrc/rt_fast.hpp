@@ -365,7 +365,7 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, cons
 // what shading needs about the hit, built after the scan from the winning record
 struct Surface {
     V3 p, n;
-    int face;   // BOX records: 2*axis + side of the face that was hit (rt_records.h)
+    int face;   // BOX records: 2*axis + side of the face that was hit (rt_records.h); per-lane path: the rt_prim that was hit (a box's face rect)
     float u, v; // only where a texture reads them
     uint32_t mat_kind;
     int32_t texture;

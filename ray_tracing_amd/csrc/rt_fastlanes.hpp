@@ -19,6 +19,7 @@
 
 #include <hip/hip_fp16.h>
 
+#include "rt_box.h"
 #include "rt_bvh.h"
 #include "rt_fast.hpp"
 
@@ -59,6 +60,18 @@ RTF_DEV bool plain_t(const rt_prim &pr, const Ray &lr, V3 inv, float dd, float i
     t = (pr.f[4] - ok) * ik;
     const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
     return (t >= t_min) & (t <= t_max) & (a >= pr.f[0]) & (a <= pr.f[1]) & (b >= pr.f[2]) & (b <= pr.f[3]);
+}
+
+// a box (rt_box.h) against the ray of its chain: where the ray enters and leaves the intersection of the three slabs.
+// The nearest of the six faces hit inside a range is tn if it lies in the range, else tf (src/box.h, hitable_list::hit).
+RTF_DEV bool box_range(V3 lo, V3 hi, const Ray &lr, V3 inv, float &tn, float &tf)
+{
+    const float x0 = (lo.x - lr.o.x) * inv.x, x1 = (hi.x - lr.o.x) * inv.x;
+    const float y0 = (lo.y - lr.o.y) * inv.y, y1 = (hi.y - lr.o.y) * inv.y;
+    const float z0 = (lo.z - lr.o.z) * inv.z, z1 = (hi.z - lr.o.z) * inv.z;
+    tn = fmax3(fminf(x0, x1), fminf(y0, y1), fminf(z0, z1));
+    tf = fmin3(fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1));
+    return tn <= tf;
 }
 
 // a plain primitive or a list (box): hitable_list::hit, src/hitable_list.h:18-34
@@ -148,6 +161,8 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, int *stack)
 
 // lanes with cur < 0 (and not NONE): leaf ~cur (rt_bvh.h: 32 bytes, what the test of a sphere or rect reads) against
 // the lane's ray.  best_prim receives the leaf's rt_prim index.
+// BOX: the tree may hold box leaves / media bounded by boxes (scenes without them skip that code altogether)
+template <bool BOX>
 RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, int *stack)
 {
     const uint4 *q = reinterpret_cast<const uint4 *>(S.leaves + ~w.cur);
@@ -181,6 +196,12 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
         h = (t >= t_min) & (t <= w.best_t) & (a >= __uint_as_float(la.x)) & (a <= __uint_as_float(la.y)) & (b >= __uint_as_float(la.z)) &
             (b <= __uint_as_float(la.w));
+    } else if (BOX && kind == RT_PRIM_GROUP) { // a box: one slab test for its six faces
+        float tn, tf;
+        const bool cut = box_range(v3(__uint_as_float(la.x), __uint_as_float(la.y), __uint_as_float(la.z)),
+                                   v3(__uint_as_float(la.w), __uint_as_float(lb.x), __uint_as_float(lb.w)), lr, inv, tn, tf);
+        t = tn >= t_min ? tn : tf;
+        h = cut & (t >= t_min) & (t <= w.best_t);
     } else { // moving sphere, constant_medium: the test reads the primitive itself
         const rt_prim &pr = S.fprims[(int)lb.z];
         if (kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment)
@@ -188,8 +209,14 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
             float t1 = 0.0f, t2 = 0.0f;
             int dummy;
             h = false;
-            if (simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
-                simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy)) {
+            bool both;
+            if (BOX && (bp.flags & RT_PRIM_IS_BOX)) { // the boundary's first hit on the whole line, then the first one after it
+                both = box_range(v3(bp.f[0], bp.f[1], bp.f[2]), v3(bp.f[3], bp.f[4], bp.f[5]), lr, inv, t1, t2) & (t2 > t1 + 0.0001f);
+            } else {
+                both = simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
+                       simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy);
+            }
+            if (both) {
                 t1 = fminf(fmaxf(t1, t_min), w.best_t);
                 if (t1 < t2) {
                     t1 = fmaxf(t1, 0.0f);
@@ -220,7 +247,7 @@ RTF_DEV bool hit_bvh(const DevScene &S, const Ray &wr, float t_min, float t_max,
     walk_start(w, wr, t_max, alive);
     while (__any(w.cur != RT_BVH_NONE)) {
         while (w.cur >= 0) walk_node(S, w, t_min, stack);
-        if (w.cur != RT_BVH_NONE) walk_leaf(S, w, wr, t_min, rng, stack);
+        if (w.cur != RT_BVH_NONE) walk_leaf<true>(S, w, wr, t_min, rng, stack);
     }
     best_t = w.best_t, best_prim = w.best_prim;
     return best_prim >= 0;
@@ -229,12 +256,32 @@ RTF_DEV bool hit_bvh(const DevScene &S, const Ray &wr, float t_min, float t_max,
 // point, normal, (u,v), material of the winner; every lane for itself
 RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int prim, Surface &s)
 {
-    const rt_prim &pr = S.fprims[prim < 0 ? 0 : prim];
+    const rt_prim *prp = &S.fprims[prim < 0 ? 0 : prim];
     s.p = fma3(t, wr.d, wr.o);
     s.u = s.v = 0.0f;
-    const int kind = pr.kind;
+    s.face = prim;
     V3 n = v3(1, 0, 0); // constant_medium: src/volume.h:47
-    if (kind != RT_PRIM_MEDIUM) {
+    if (prp->kind == RT_PRIM_GROUP) { // a box: the face whose plane holds the point, its outward normal, its rect's material
+        const Ray lr = prp->chain == 0 ? wr : rt::chain_down(S, prp->chain, wr);
+        const V3 pl = fma3(t, lr.d, lr.o);
+        const V3 lo = v3(prp->f[0], prp->f[1], prp->f[2]), hi = v3(prp->f[3], prp->f[4], prp->f[5]);
+        const V3 q = v3(pl.x - 0.5f * (lo.x + hi.x), pl.y - 0.5f * (lo.y + hi.y), pl.z - 0.5f * (lo.z + hi.z));
+        const float ex = fabsf(q.x) - 0.5f * (hi.x - lo.x), ey = fabsf(q.y) - 0.5f * (hi.y - lo.y), ez = fabsf(q.z) - 0.5f * (hi.z - lo.z);
+        const bool is_x = (ex >= ey) & (ex >= ez), is_y = !is_x & (ey >= ez);
+        const int axis = is_x ? 0 : is_y ? 1 : 2;
+        const float qa = is_x ? q.x : is_y ? q.y : q.z;
+        const float sg = qa < 0.0f ? -1.0f : 1.0f;
+        n = v3(is_x ? sg : 0.0f, is_y ? sg : 0.0f, (is_x | is_y) ? 0.0f : sg);
+        if (prp->chain != 0) {
+            V3 dummy = pl;
+            rt::chain_up(S, prp->chain, dummy, n);
+        }
+        s.face = prp->first + 2 * axis + (qa < 0.0f ? 0 : 1);
+        prp = &S.fprims[s.face];
+    }
+    const rt_prim &pr = *prp;
+    const int kind = pr.kind;
+    if ((kind != RT_PRIM_MEDIUM) & (s.face == prim)) {
         const Ray lr = pr.chain == 0 ? wr : rt::chain_down(S, pr.chain, wr);
         const V3 pl = fma3(t, lr.d, lr.o);
         if (kind <= RT_PRIM_MOVING_SPHERE) {

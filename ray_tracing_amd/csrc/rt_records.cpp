@@ -1,6 +1,8 @@
 // rt_records.cpp -- builds the register-resident record table (rt_records.h) from a scene description.
 #include "rt_records.h"
 
+#include "rt_box.h"
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -44,38 +46,6 @@ void chain_up_normal(const rt_scene_desc *d, int chain, float n[3])
             n[2] = -s * nx + co * nz;
         }
     }
-}
-
-// Is this list the reference's box (src/box.h:19-31)?  Six rects, two per axis, that span p0..p1, the one at p0 of each
-// pair with its normal flipped (outward normals), one material.  face[2*axis + side]: the member that is that face.
-bool as_box(const rt_scene_desc *d, const rt_prim &g, float lo[3], float hi[3], int face[6])
-{
-    if (g.kind != RT_PRIM_GROUP || g.count != 6) return false;
-    for (int k = 0; k < 6; ++k) face[k] = -1;
-    for (int k = 0; k < 6; ++k) {
-        const rt_prim &c = d->prims[g.first + k];
-        int axis; // the axis the rect is normal to
-        if (c.kind == RT_PRIM_YZ_RECT) axis = 0;
-        else if (c.kind == RT_PRIM_XZ_RECT) axis = 1;
-        else if (c.kind == RT_PRIM_XY_RECT) axis = 2;
-        else return false;
-        if (c.material != d->prims[g.first].material || (c.flags & RT_PRIM_NEEDS_UV)) return false;
-        const int slot = 2 * axis + ((c.flags & RT_PRIM_FLIP) ? 0 : 1);
-        if (face[slot] >= 0) return false;
-        face[slot] = g.first + k;
-    }
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = d->prims[face[2 * a]].f[4], hi[a] = d->prims[face[2 * a + 1]].f[4];
-        if (!(lo[a] < hi[a])) return false;
-    }
-    // a yz rect spans (y, z), an xz rect (x, z), an xy rect (x, y): src/plane.h
-    static const int A[3] = {1, 0, 0}, B[3] = {2, 2, 1};
-    for (int k = 0; k < 6; ++k) {
-        const float *f = d->prims[face[k]].f;
-        const int a = k / 2;
-        if (f[0] != lo[A[a]] || f[1] != hi[A[a]] || f[2] != lo[B[a]] || f[3] != hi[B[a]]) return false;
-    }
-    return true;
 }
 
 // the light records (important_hitables), from record `at` on; returns the index after them
@@ -130,7 +100,7 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
     for (int e = 0; e < d->n_entries; ++e)
         if ((d->entries[e].b & 255) == RT_ENTRY_LEAF) {
             const rt_prim &p = d->prims[d->entries[e].a];
-            n_leaf_records += p.kind == RT_PRIM_GROUP && !as_box(d, p, box_lo, box_hi, box_face) ? p.count : 1;
+            n_leaf_records += p.kind == RT_PRIM_GROUP && !rt_as_box(d, p, box_lo, box_hi, box_face) ? p.count : 1;
         }
     // (RT_AMD_RECORDS_KEEP_BOXES: test aid -- small scenes keep their box records too, so the tests reach the generic scan)
     const bool keep_inner = n_leaf_records > RT_REC_FLAT_LEAVES || getenv("RT_AMD_RECORDS_KEEP_BOXES") != nullptr;
@@ -144,7 +114,7 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             continue;
         }
         const rt_prim &p = d->prims[en.a];
-        if (as_box(d, p, box_lo, box_hi, box_face)) { // one slab test instead of six rect tests
+        if (rt_as_box(d, p, box_lo, box_hi, box_face)) { // one slab test instead of six rect tests
             use_chain(p.chain);
             n_stream += 2;
         } else if (p.kind == RT_PRIM_GROUP) {
@@ -254,7 +224,7 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             continue;
         }
         const rt_prim &p = d->prims[en.a];
-        if (as_box(d, p, box_lo, box_hi, box_face)) {
+        if (rt_as_box(d, p, box_lo, box_hi, box_face)) {
             // The nearest of the six faces inside (t_min, best] is where the ray enters the slabs' intersection, or where
             // it leaves it when the entry lies before t_min: the scan does that one test (rt_fast.hpp) and the face is
             // named afterwards from the hit point, with what the second record holds.

@@ -2,6 +2,7 @@
 // Includes the builder's source to reach its internals (the directed float -> half rounding).
 #include "../../ray_tracing_amd/csrc/rt_bvh.cpp"
 #include "../../ray_tracing_amd/csrc/rt_order.h"
+#include "../../ray_tracing_amd/csrc/rt_box.h"
 #include "../../include/rt_host.h"
 
 #include <cstdio>
@@ -95,9 +96,11 @@ int main(int argc, char **argv)
         for (int e = 0; e < d->n_entries; ++e) {
             if ((d->entries[e].b & 255) != RT_ENTRY_LEAF) continue;
             const rt_prim &p = d->prims[d->entries[e].a];
-            if (p.kind == RT_PRIM_GROUP) {
+            float blo[3], bhi[3];
+            int bface[6];
+            if (p.kind == RT_PRIM_GROUP && !rt_as_box(d, p, blo, bhi, bface)) {
                 for (int k = 0; k < p.count; ++k) st.missing += seen[p.first + k] != 1;
-            } else {
+            } else { // (a list that is a box is one leaf)
                 st.missing += seen[d->entries[e].a] != 1;
             }
         }
