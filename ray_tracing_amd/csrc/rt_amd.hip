@@ -641,10 +641,10 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 16
 #endif
-// Five waves per SIMD is what the LDS stacks allow (five blocks per CU); the textured kernel would take 101 VGPRs (four
-// waves) if left alone, held to 96 it runs Next-Week final 9 % faster.
+// Six waves per SIMD is what the LDS stacks allow (six blocks per CU, rt_bvh.h); left alone the kernels take 89 / 101 VGPRs
+// (five / four waves).  Held to 80: random spheres +10 %, Next-Week final +12 %, 1M spheres +4 %.
 #ifndef RT_LANES_WAVES_PER_EU
-#define RT_LANES_WAVES_PER_EU 5
+#define RT_LANES_WAVES_PER_EU 6
 #endif
 template <bool TEX, bool BOX>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)

@@ -18,7 +18,12 @@
 
 /* child reference: >= 0 inner node index; < 0 leaf: ~ref is an rt_leaf index; RT_BVH_NONE: no child */
 #define RT_BVH_NONE ((int32_t)0x80000000)
-#define RT_BVH_MAX_DEPTH 28 /* pending far children per lane: the stack in LDS (28 levels x 4 waves still fit five blocks per CU) */
+#ifndef RT_BVH_MAX_DEPTH
+#define RT_BVH_MAX_DEPTH 23
+#endif
+/* pending far children per lane: the stack in LDS.  23 levels x 64 lanes x 4 B x 4 waves + the tile sums = 26 KiB per block:
+ * six blocks per CU, six waves per SIMD.  (28 levels leave the builder freer on the 1M-sphere scene but hold a SIMD to five
+ * waves: measured 3-10 % slower on every scene.) */
 
 /* Inner node, 32 bytes (two dwordx4 loads from one cache line): the boxes of both children as IEEE half floats, rounded
  * outwards (lo down, hi up; beyond the half range they become -inf / +inf), and the two child references.  The walk
