@@ -134,7 +134,7 @@ def main():
     if rank == 0:
         from ray_tracing_amd import _capi
         # the Cornell box fits the record table and has no textures: rt_render runs it on render_fast_block_kernel
-        kernel = ("render_fast_block_kernel" if scene.info(_capi.RT_INFO_LAST_RENDER_PATH) == _capi.RT_PATH_FAST else "render_kernel")
+        kernel = ("render_fast_block_kernel" if scene.info(_capi.RT_INFO_LAST_RENDER_PATH) == _capi.RT_PATH_FAST else "render_kernel_uniform")
         sec_per_step = dt / a.steps
         paths = nx * ny * spp
         value = paths / sec_per_step / 1e6

@@ -1,13 +1,15 @@
 // rt_amd.hip -- kernels and C-ABI entry points of include/rt_amd.h (gfx950).
 //
 // Kernels
-//   render_kernel   the per-pixel Monte Carlo loop: replaces compute_one_sample_task::run
+//   render_kernel_uniform / render_kernel_lanes (exact path, body render_exact), render_fast_kernel,
+//   render_fast_block_kernel, render_fastlanes_kernel (fast paths)
+//                   the per-pixel Monte Carlo loop: replaces compute_one_sample_task::run
 //                   (src/main.cpp:217-245) + color() (src/main.cpp:91-127) + the thread pool.
 //   resolve_kernel  src/main.cpp:708-743.
 //   trace_kernel    world->hit() for a batch of rays (the parity surface).
 //   camera_kernel   camera::get_ray for a batch of samples.
 //
-// render_kernel: one wave64 owns one task = (8x8 pixel tile, range of samples).
+// render_exact: one wave64 owns one task = (8x8 pixel tile, range of samples).
 // The wave keeps 64 paths in registers, one per lane.  Each iteration of its loop
 //   1. refills dead lanes from the task's pool of (pixel, sample) items: a ballot of
 //      the dead lanes, a prefix count (mbcnt) to give each a distinct item, ray
@@ -103,7 +105,7 @@ __device__ __forceinline__ bool closest_hit(const DevScene &S, const Ray &r, flo
 
 // LANES: per-lane walk of the tree instead of the wave-uniform one (world_hit)
 template <bool LANES>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_kernel(DevScene S, RenderArgs A, float *__restrict__ accum)
+__device__ __forceinline__ void render_exact(DevScene S, RenderArgs A, float *__restrict__ accum)
 {
     __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
     const int lane = threadIdx.x & 63;
@@ -199,6 +201,13 @@ __global__ void resolve_kernel(const float4 *__restrict__ accum, int n, uint32_t
     }
     out[i] = 0xff000000u | (q[2] << 16) | (q[1] << 8) | q[0];
 }
+
+// The wave-uniform walk takes 130 VGPRs if left alone (three waves per SIMD); held to 128 it runs at four (+17 %).  The
+// per-lane walk is bound by its LDS stacks and keeps the compiler's choice.
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void render_kernel_uniform(DevScene S, RenderArgs A, float *__restrict__ accum) { render_exact<false>(S, A, accum); }
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void render_kernel_lanes(DevScene S, RenderArgs A, float *__restrict__ accum) { render_exact<true>(S, A, accum); }
 
 template <bool LANES>
 __global__ __launch_bounds__(256) void trace_kernel(DevScene S, int n, const float *__restrict__ rays, float t_min, float t_max,
@@ -1106,9 +1115,9 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
             hipLaunchKernelGGL((render_fast_kernel<false, false>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
     }
     else if (s->dev.n_entries > RT_UNIFORM_WALK_MAX)
-        hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
+        hipLaunchKernelGGL(render_kernel_lanes, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
     else
-        hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
+        hipLaunchKernelGGL(render_kernel_uniform, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, A, d_accum);
     RT_HIP(hipGetLastError());
     s->last_render_path = use_fast ? RT_PATH_FAST : RT_PATH_EXACT;
     RT_HIP(hipEventRecord(s->ev1, stream));

@@ -1,8 +1,12 @@
+#!/usr/bin/env python3
+"""Exact against fast render path, kernel time from HIP events.  usage: path_bench.py [scene:nx:ny:spp ...]"""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ray_tracing_amd import api, _capi
-for name, nx, ny, spp in [("cornell_box_volumes", 512, 512, 64), ("simple_scene", 512, 512, 64), ("another_simple", 512, 512, 64)]:
+jobs = sys.argv[1:] or ["cornell_box_volumes:512:512:64", "simple_scene:512:512:64", "another_simple:512:512:64"]
+for job in jobs:
+    name, nx, ny, spp = job.split(":"); nx, ny, spp = int(nx), int(ny), int(spp)
     for path in (_capi.RT_PATH_EXACT, _capi.RT_PATH_FAST):
         sc = api.Scene(api.HostScene(name, nx / ny), 0)
         try:
