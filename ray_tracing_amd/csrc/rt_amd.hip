@@ -52,6 +52,7 @@ struct RenderArgs {
     uint32_t seed;
     int32_t atomic_out;    // 1: add into accum with atomics (several tasks per pixel or ACCUMULATE)
     int32_t n_tasks;
+    int32_t stack_levels;  // per-lane fast path: inner levels of the tree = levels of the LDS stacks (dynamic LDS)
 };
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -662,7 +663,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                                                                                  rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
 {
     __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
-    __shared__ int bvh_stacks[WAVES_PER_BLOCK][RT_BVH_MAX_DEPTH * 64];
+    extern __shared__ int bvh_stacks[]; // [WAVES_PER_BLOCK][A.stack_levels][64], sized by the launch
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -677,7 +678,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
 
     float *acc = tile_acc[wave];
     acc[lane] = 0.0f, acc[64 + lane] = 0.0f, acc[128 + lane] = 0.0f;
-    int *stack = &bvh_stacks[wave][lane];
+    int *stack = &bvh_stacks[wave * A.stack_levels * 64 + lane];
 
     int next = 0;
     bool alive = false;
@@ -753,7 +754,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
 }
 
 __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n, const float *__restrict__ rays, float t_min, float t_max,
-                                                              uint32_t seed, rt_hit *__restrict__ out)
+                                                              uint32_t seed, int stack_levels, rt_hit *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool alive = i < n;
@@ -761,8 +762,8 @@ __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n,
     const float *f = rays + 7 * (size_t)k;
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
     Rng rng{rt_path_key(seed, (uint32_t)k, 0u)};
-    __shared__ int bvh_stacks[4][RT_BVH_MAX_DEPTH * 64];
-    int *stack = &bvh_stacks[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][threadIdx.x & 63];
+    extern __shared__ int bvh_stacks[]; // [4][stack_levels][64]
+    int *stack = &bvh_stacks[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * stack_levels * 64 + (threadIdx.x & 63)];
     float t;
     int prim;
     const bool any = rtf::hit_bvh(S, r, t_min, t_max, alive, rng, t, prim, stack);
@@ -798,6 +799,7 @@ struct rt_scene {
     bool fast_flat = false;     // the record stream holds no box records and is stored in runs
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     bool lanes_boxes = false;   // its tree holds box leaves or media bounded by boxes (rt_box.h)
+    int bvh_levels = 1;         // inner levels of that tree (rt_bvh_build)
     const char *fast_why = "";
     rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids and 64 x 6 face ids (inside blob)
@@ -995,6 +997,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     for (int m = 0; fast_ok && m < d->n_materials; ++m)
         s->fast_textured |= (int32_t)tab.rec[tab.materials_base + m][1] >= 0;
     s->lanes_ok = lanes_ok;
+    s->bvh_levels = lanes_ok && bvh_depth > 0 ? bvh_depth : 1;
     for (const rt_prim &fp : fprims) s->lanes_boxes |= (fp.flags & RT_PRIM_IS_BOX) != 0;
     for (int m = 0; lanes_ok && m < d->n_materials; ++m)
         s->fast_textured |= d->materials[m].texture >= 0 && d->textures[d->materials[m].texture].kind != RT_TEX_CONSTANT;
@@ -1056,7 +1059,7 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     const bool block_off = getenv("RT_AMD_NO_BLOCK_KERNEL") != nullptr; // tuning / test aid: the wave kernel instead
     const bool block_kernel = use_fast && s->fast_ok && !s->fast_textured && !block_off && p->max_depth < 65536 && s->layout.n_lights <= 16;
     const int tile_w = block_kernel ? 4 * BLOCK_WAVES : 8, tile_h = block_kernel ? 16 : 8, waves_per_task = block_kernel ? BLOCK_WAVES : 1;
-    RenderArgs A;
+    RenderArgs A{};
     A.nx = p->nx, A.ny = p->ny;
     A.tiles_x = (p->nx + tile_w - 1) / tile_w, A.tiles_y = (p->ny + tile_h - 1) / tile_h;
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
@@ -1090,14 +1093,16 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     RT_HIP(hipEventRecord(s->ev0, stream));
     if (use_fast && s->lanes_ok) {
         const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
+        const size_t lds = (size_t)WAVES_PER_BLOCK * s->bvh_levels * 256; // the walks' stacks
+        A.stack_levels = s->bvh_levels;
         if (s->fast_textured && s->lanes_boxes)
-            hipLaunchKernelGGL((render_fastlanes_kernel<true, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<true, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
         else if (s->fast_textured)
-            hipLaunchKernelGGL((render_fastlanes_kernel<true, false>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<true, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
         else if (s->lanes_boxes)
-            hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
         else
-            hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
     } else if (use_fast && block_kernel) {
         if (s->fast_flat)
             hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
@@ -1207,7 +1212,7 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
     if (e == hipSuccess) e = hipMemcpy(d_rays, h_rays, 28 * N, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         if (s->trace_path == RT_PATH_FAST && s->lanes_ok)
-            hipLaunchKernelGGL(trace_fastlanes_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
+            hipLaunchKernelGGL(trace_fastlanes_kernel, dim3((n + 255) / 256), dim3(256), (size_t)4 * s->bvh_levels * 256, nullptr, s->dev, n, d_rays, t_min, t_max, seed, s->bvh_levels, d_hits);
         else if (s->trace_path == RT_PATH_FAST)
             hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
                                d_rays, t_min, t_max, d_hits);

@@ -121,6 +121,7 @@ struct Builder {
     std::vector<Item> items;
     std::vector<Node32> *nodes;
     int max_depth = 0;
+    int limit = RT_BVH_MAX_DEPTH; // inner levels the tree may have
     bool ok = true;
 
     static int log2_ceil(size_t n)
@@ -134,7 +135,7 @@ struct Builder {
     int32_t build(size_t a, size_t b, int depth)
     {
         max_depth = std::max(max_depth, depth);
-        if (depth > RT_BVH_MAX_DEPTH) return ok = false, 0;
+        if (depth > limit) return ok = false, 0;
         const int32_t me = (int32_t)nodes->size();
         nodes->push_back(Node32{});
         const size_t n = b - a;
@@ -146,7 +147,7 @@ struct Builder {
         for (int k = 1; k < 3; ++k)
             if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
         // the stack bound: once the remaining depth only just fits a balanced tree, split at the median
-        const bool force_median = depth + log2_ceil(n) >= RT_BVH_MAX_DEPTH - 1;
+        const bool force_median = depth + log2_ceil(n) >= limit - 1;
         bool split_done = false;
         if (!force_median && n > 2) {
             constexpr int NB = 16;
@@ -320,7 +321,13 @@ bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::
         tree.push_back(nd);
         *depth = 1;
     } else {
+        const std::vector<Item> items = B.items; // build() permutes them
         B.build(0, B.items.size(), 1);
+        if (!B.ok) { // too many primitives for the preferred bound: the deeper stack (five waves per SIMD)
+            tree.clear();
+            B.items = items, B.ok = true, B.max_depth = 0, B.limit = RT_BVH_DEPTH_LIMIT;
+            B.build(0, B.items.size(), 1);
+        }
         *depth = B.max_depth;
         if (!B.ok) return false;
     }

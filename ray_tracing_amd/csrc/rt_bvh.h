@@ -18,12 +18,16 @@
 
 /* child reference: >= 0 inner node index; < 0 leaf: ~ref is an rt_leaf index; RT_BVH_NONE: no child */
 #define RT_BVH_NONE ((int32_t)0x80000000)
+/* Pending far children per lane live in a stack in LDS, one level per inner level of the tree (rt_bvh_build reports how
+ * many the tree has; the kernels size their dynamic LDS from it).  23 levels x 64 lanes x 4 B x 4 waves + the tile sums =
+ * 26 KiB per block: six blocks per CU, six waves per SIMD -- the builder keeps to RT_BVH_MAX_DEPTH if it can (median
+ * splits once the remaining levels only just fit a balanced tree; enough for 4M primitives).  28 levels leave it freer on
+ * the 1M-sphere scene but hold a SIMD to five waves: measured 3-10 % slower on every scene.  Beyond 4M primitives it
+ * falls back to RT_BVH_DEPTH_LIMIT. */
 #ifndef RT_BVH_MAX_DEPTH
 #define RT_BVH_MAX_DEPTH 23
 #endif
-/* pending far children per lane: the stack in LDS.  23 levels x 64 lanes x 4 B x 4 waves + the tile sums = 26 KiB per block:
- * six blocks per CU, six waves per SIMD.  (28 levels leave the builder freer on the 1M-sphere scene but hold a SIMD to five
- * waves: measured 3-10 % slower on every scene.) */
+#define RT_BVH_DEPTH_LIMIT 28
 
 /* Inner node, 32 bytes (two dwordx4 loads from one cache line): the boxes of both children as IEEE half floats, rounded
  * outwards (lo down, hi up; beyond the half range they become -inf / +inf), and the two child references.  The walk
@@ -52,8 +56,9 @@ typedef struct rt_leaf {
  * receives the primitive table rt_leaf.prim indexes: a copy of d->prims in which spheres under a rigid instance chain
  * are moved to world space (chain 0; not those whose texture reads (u,v), which is defined in the sphere's own frame)
  * and boxes carry RT_PRIM_IS_BOX, their corners and their faces in canonical order (rt_box.h).
- * Returns false when it cannot (a depth bound it could not keep, non-finite boxes, more than 2^24 chains); the caller
- * then has no fast path for large scenes. */
+ * `depth` receives the number of inner levels (= stack levels a walk needs).
+ * Returns false when it cannot (not even RT_BVH_DEPTH_LIMIT levels suffice, non-finite boxes, more than 2^24 chains); the
+ * caller then has no fast path for large scenes. */
 bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::vector<rt_leaf> &leaves, std::vector<rt_prim> &prims,
                   int *depth);
 

@@ -109,7 +109,7 @@ int main(int argc, char **argv)
         const bool ordered = rt_order_build(d, order, &odepth);
         printf("%s: ok=%d nodes=%d leaves=%d depth=%d(%d) bad_box=%d dup=%d missing=%d | reference tree: entries=%d binary=%d depth=%d\n",
                argv[a], ok, st.nodes, st.leaves, st.depth, depth, st.bad_box, st.dup, st.missing, d->n_entries, ordered, odepth);
-        if (!ok || st.bad_box || st.dup || st.missing || st.depth > RT_BVH_MAX_DEPTH || (int)leaves.size() != st.leaves || !ordered) ++failures;
+        if (!ok || st.bad_box || st.dup || st.missing || st.depth > depth + 1 || depth > RT_BVH_DEPTH_LIMIT || (int)leaves.size() != st.leaves || !ordered) ++failures;
         rt_host_scene_free(h);
     }
     printf("failures: %d\n", failures);
