@@ -24,6 +24,7 @@
 // registers, SGPRs and 1 KiB of LDS per wave.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1067,13 +1068,19 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     // tasks than the chip holds waves (7168 at 7 waves/SIMD) and the hardware dispatcher balances
     // them; measured on Cornell 1024x1024x1024spp: 16 Ki tasks 5.1, 128 Ki 6.9, 256 Ki 7.0, 1 Mi 6.3
     // Gpaths/s.  Each task keeps at least 16 paths per lane so that the drain of its pool (a few
-    // long paths finishing alone) stays small beside its body.
+    // long paths finishing alone) stays small beside its body -- 8 when that leaves too few tasks
+    // (16-spp renders, 16 / 8 / 4 paths per lane: Next-Week final 0.71 / 0.89 / 0.96, random spheres
+    // 3.5 / 4.3 / 4.5, Cornell 8.6 / 9.3 / 8.3 Gpaths/s; with enough tasks 16 is the better: random
+    // spheres at 64 spp 6.4 against 5.9).
     int64_t target_tasks = 262144;
     if (const char *e = getenv("RT_AMD_TARGET_TASKS")) target_tasks = atoll(e) > 0 ? atoll(e) : target_tasks; // tuning aid
     target_tasks /= waves_per_task;
     int64_t want_chunks = (target_tasks + tiles - 1) / tiles;
-    int64_t max_chunks = ((int64_t)ns * p->sub_samples + 15) / 16;
-    if (want_chunks > max_chunks) want_chunks = max_chunks;
+    const int64_t all_paths = (int64_t)ns * p->sub_samples;
+    const int64_t want = want_chunks, cap16 = (all_paths + 15) / 16, cap8 = (all_paths + 7) / 8;
+    if (want_chunks > cap16) want_chunks = cap16;
+    const int64_t few = 49152 / waves_per_task; // below this many tasks the end of the launch shows: go down to 8 paths per lane
+    if (tiles * want_chunks < few) want_chunks = std::min(std::min((few + tiles - 1) / tiles, cap8), want);
     if (want_chunks > ns) want_chunks = ns;
     if (want_chunks < 1) want_chunks = 1;
     {   // a task's pool is counted in 32 bits (up to 512 items per sample in the block kernel)
