@@ -400,10 +400,14 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     __shared__ int4 cnt[NW];     // [wave].{x,y,z,w} = lanes of class 0..3
     __shared__ unsigned pool_next;
     __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
+    // the camera is only needed by the refill: read from LDS there, it does not hold 24 SGPRs for the whole kernel
+    // (the kernel is held to 80 SGPRs for eight waves per SIMD)
+    __shared__ __align__(16) rt_camera lcam;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int task = blockIdx.x;
     for (int k = tid; k < (RT_REC_MAX + 1) * 8; k += NT) lrecs[k] = recs[k];
+    if (tid < (int)(sizeof(rt_camera) / 4)) reinterpret_cast<uint32_t *>(&lcam)[tid] = reinterpret_cast<const uint32_t *>(&S.cam)[tid];
     rtf::Regs R;
     load_records(recs, lane, R);
 
@@ -447,9 +451,10 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                         const int j = A.ny - 1 - row;
                         const float u = (float(col) + rng.next()) * inv_nx;
                         const float v = (float(j) + rng.next()) * inv_ny;
-                        const V3 disk = S.cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
+                        const rt_camera cam = lcam;
+                        const V3 disk = cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
                         const float time01 = rng.next();
-                        const Ray r = rtf::camera_ray(S.cam, u, v, disk, time01);
+                        const Ray r = rtf::camera_ray(cam, u, v, disk, time01);
                         o = r.o, d = r.d, time = r.time;
                         T = v3(1, 1, 1);
                         depth = 0;
