@@ -388,35 +388,60 @@ constexpr int BLOCK_WAVES = RT_BLOCK_WAVES;
 #define RT_BLOCK_WAVES_PER_EU 8
 #endif
 // NW waves per block; the tile is (4*NW) x 16 pixels
-template <bool FLAT, int NW>
+// CHAIN: the block does not end with its task.  When the task's pool is empty it adds the tile's sums to the image, takes the
+// next task from a counter in memory (`next_task`, zeroed by the host) and refills from that pool at once, while the last
+// paths of the previous task are still on their way: those add their radiance to the image directly.  Without this the
+// lanes of a block idle while the longest of its last paths finish (a quarter of a 16-paths-per-lane task).
+template <bool FLAT, int NW, bool CHAIN>
 __global__ __launch_bounds__(64 * NW)
 __attribute__((amdgpu_waves_per_eu(RT_BLOCK_WAVES_PER_EU, RT_BLOCK_WAVES_PER_EU)))
 void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf::Layout Y,
-                                                                RenderArgs A, float *__restrict__ accum)
+                                                                RenderArgs A, float *__restrict__ accum, unsigned *__restrict__ next_task)
 {
     constexpr int NT = 64 * NW, TW = 4 * NW; // threads = pixels of the tile; tile width
     __shared__ float acc[3 * NT];
     __shared__ uint4 xch[3][NT]; // the path state in three 16-byte pieces, [piece][slot]
     __shared__ int4 cnt[NW];     // [wave].{x,y,z,w} = lanes of class 0..3
     __shared__ unsigned pool_next;
+    __shared__ int n_old[NW];    // [wave] live lanes that still belong to the previous task (CHAIN)
+    __shared__ int task_now;     // the task the pool belongs to (CHAIN)
     __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
     // the camera is only needed by the refill: read from LDS there, it does not hold 24 SGPRs for the whole kernel
     // (the kernel is held to 80 SGPRs for eight waves per SIMD)
     __shared__ __align__(16) rt_camera lcam;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int task = blockIdx.x;
+    int task = blockIdx.x; // CHAIN: the first one; the counter hands out gridDim.x, gridDim.x + 1, ...
     for (int k = tid; k < (RT_REC_MAX + 1) * 8; k += NT) lrecs[k] = recs[k];
     if (tid < (int)(sizeof(rt_camera) / 4)) reinterpret_cast<uint32_t *>(&lcam)[tid] = reinterpret_cast<const uint32_t *>(&S.cam)[tid];
     rtf::Regs R;
     load_records(recs, lane, R);
 
-    const int tile = task / A.n_chunks, chunk = task - tile * A.n_chunks;
-    const int tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x; // TW x 16 tiles
-    const int s0 = chunk * A.chunk_samples;
-    const int s1 = min(s0 + A.chunk_samples, A.n_samples);
-    const unsigned total = (unsigned)NT * (unsigned)((s1 - s0) * A.sub_samples);
-    const float inv_nx = 1.0f / float(A.nx), inv_ny = 1.0f / float(A.ny);
+    int tile_x, tile_y, s0, s1; // TW x 16 tiles
+    unsigned total;
+    int old_tile_x = 0, old_tile_y = 0; // CHAIN: where the paths of the previous task belong
+    auto open_task = [&](int tk) {
+        const int tile = tk / A.n_chunks, chunk = tk - tile * A.n_chunks;
+        tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
+        s0 = chunk * A.chunk_samples;
+        s1 = min(s0 + A.chunk_samples, A.n_samples);
+        total = tk < A.n_tasks ? (unsigned)NT * (unsigned)((s1 - s0) * A.sub_samples) : 0u;
+    };
+    open_task(task);
+    const float inv_nx = 1.0f / float(A.nx), inv_ny = 1.0f / float(A.ny), inv_sub = 1.0f / (float)A.sub_samples;
+    // the tile's sums -> the image: [A, B, G, R] per pixel (src/main.cpp:238-242), a tile row is TW x 16 contiguous bytes
+    auto flush = [&](bool with_atomics) {
+        const int col = tile_x * TW + (tid % TW), row = tile_y * 16 + (tid / TW);
+        if (col < A.nx && row < A.ny) {
+            float *dst = accum + 4 * ((size_t)row * A.nx + col);
+            const float v4[4] = {(float)(s1 - s0), acc[2 * NT + tid] * inv_sub, acc[NT + tid] * inv_sub, acc[tid] * inv_sub};
+            if (with_atomics) {
+                for (int c = 0; c < 4; ++c) atomicAdd(dst + c, v4[c]);
+            } else {
+                *reinterpret_cast<float4 *>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            }
+        }
+    };
 
     acc[tid] = 0.0f, acc[NT + tid] = 0.0f, acc[2 * NT + tid] = 0.0f;
     if (tid == 0) pool_next = 0u;
@@ -428,6 +453,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     Rng rng{0u};
     int depth = 0, pix = tid;
     int turn = 0;
+    int old = 0; // CHAIN: 1 = this lane's path belongs to the previous task
 
     for (;;) {
         // ---- refill: dead lanes (together in the last waves after the regroup) take items from the block's pool --------
@@ -459,6 +485,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                         T = v3(1, 1, 1);
                         depth = 0;
                         alive = true;
+                        old = 0;
                     }
                 }
             }
@@ -490,9 +517,16 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                 alive = false;
                 if (rec >= 0 && mat_kind == RT_MAT_DIFFUSE_LIGHT) { // radiance = T * emitted; de_nan, src/vec3.h:184-191
                     const V3 L = v3(T.x * mcol.x, T.y * mcol.y, T.z * mcol.z);
-                    if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
-                    if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[NT + pix], L.y);
-                    if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[2 * NT + pix], L.z);
+                    if (CHAIN && old) { // a path of the previous task: its tile has gone to the image already
+                        float *dst = accum + 4 * ((size_t)(old_tile_y * 16 + pix / TW) * A.nx + (old_tile_x * TW + pix % TW));
+                        if (L.x == L.x && L.x != 0.0f) atomicAdd(dst + 3, L.x * inv_sub);
+                        if (L.y == L.y && L.y != 0.0f) atomicAdd(dst + 2, L.y * inv_sub);
+                        if (L.z == L.z && L.z != 0.0f) atomicAdd(dst + 1, L.z * inv_sub);
+                    } else {
+                        if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
+                        if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[NT + pix], L.y);
+                        if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[2 * NT + pix], L.z);
+                    }
                 }
             } else {
                 ++depth;
@@ -514,6 +548,10 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         const unsigned long long mine = cls == 0 ? b0 : cls == 1 ? b1 : cls == 2 ? b2 : ~(b0 | b1 | b2);
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
         if (lane == 0) cnt[wave] = make_int4(__popcll(b0), __popcll(b1), __popcll(b2), 64 - __popcll(b0 | b1 | b2));
+        if (CHAIN) {
+            const int n = __popcll(__ballot(cls != 3 && old != 0));
+            if (lane == 0) n_old[wave] = n;
+        }
         __syncthreads();
         int before = 0, n_dead = 0; // slots of lower classes + slots of my class in lower waves
 #pragma unroll
@@ -530,9 +568,14 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         const uint32_t packed = (uint32_t)depth | ((uint32_t)pix << 16) | ((uint32_t)cls << 25) | ((uint32_t)to_light << 27) | ((uint32_t)light << 28);
         xch[0][dst] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(d.x));
         xch[1][dst] = make_uint4(__float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(T.x), __float_as_uint(T.y));
-        xch[2][dst] = make_uint4(__float_as_uint(T.z), rng.x, packed, (uint32_t)src);
+        xch[2][dst] = make_uint4(__float_as_uint(T.z), rng.x, packed, (uint32_t)src | ((uint32_t)old << 8));
+        int old_alive = 0;
+        if (CHAIN) {
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) old_alive += n_old[w2];
+        }
         __syncthreads();
-        if (n_dead == NT && pool_now >= total) break; // the same for every wave of the block
+        if (!CHAIN && n_dead == NT && pool_now >= total) break; // the same for every wave of the block
         // The slots are sorted by class, so read in place wave 0 would always get the costliest paths and the last wave the
         // waiting lanes -- and a block's waves sit on different SIMDs.  The block therefore reads the slots rotated by one
         // wave more every round: each SIMD sees every class in turn.
@@ -544,11 +587,30 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         T = v3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
         rng.x = q2.y;
         const uint32_t word = q2.z;
-        const int hit_rec = (int)q2.w;
+        const int hit_rec = (int)(q2.w & 255u);
+        old = (int)((q2.w >> 8) & 1u);
         depth = (int)(word & 0xffffu), pix = (int)((word >> 16) & 511u), cls = (int)((word >> 25) & 3u);
         to_light = (int)((word >> 27) & 1u), light = (int)(word >> 28);
         alive = cls != 3;
         o = p;
+        if (CHAIN && pool_now >= total) { // the pool is empty (the same finding in every wave of the block)
+            if (task >= A.n_tasks) { // nothing left to take
+                if (n_dead == NT) break;
+            } else if (old_alive == 0) {
+                // the tile goes to the image, the paths still on their way become the previous task's, the next task opens
+                flush(true);
+                acc[tid] = 0.0f, acc[NT + tid] = 0.0f, acc[2 * NT + tid] = 0.0f;
+                old_tile_x = tile_x, old_tile_y = tile_y;
+                old = alive ? 1 : 0;
+                if (tid == 0) {
+                    task_now = (int)(atomicAdd(next_task, 1u) + gridDim.x);
+                    pool_next = 0u;
+                }
+                __syncthreads();
+                task = task_now;
+                open_task(task);
+            }
+        }
 
         // ---- shade: the lanes of a wave now mostly share a class -------------------------------------------------------------
         if (__any(alive)) {
@@ -594,20 +656,9 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         }
     }
 
-    // ---- tile sums -> HBM: [A, B, G, R] per pixel (src/main.cpp:238-242), a tile row is TW x 16 contiguous bytes ----------
-    {
-        const float inv = 1.0f / (float)A.sub_samples;
-        const int col = tile_x * TW + (tid % TW), row = tile_y * 16 + (tid / TW);
-        if (col < A.nx && row < A.ny) {
-            float *dst = accum + 4 * ((size_t)row * A.nx + col);
-            const float v4[4] = {(float)(s1 - s0), acc[2 * NT + tid] * inv, acc[NT + tid] * inv, acc[tid] * inv};
-            if (A.atomic_out) {
-                for (int k = 0; k < 4; ++k) atomicAdd(dst + k, v4[k]);
-            } else {
-                *reinterpret_cast<float4 *>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
-            }
-        }
-    }
+    if (!CHAIN) flush(A.atomic_out != 0); // CHAIN: every tile went out when the block moved on, the last one included (its pool
+                                         // was empty, nothing was left to take: flushed below)
+    if (CHAIN) flush(true);
 }
 
 // world->hit() on the record table (what render_fast_kernel's bounces see)
@@ -810,6 +861,8 @@ struct rt_scene {
     rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids and 64 x 6 face ids (inside blob)
     int32_t *d_rec_user = nullptr;
+    unsigned *d_task_counter = nullptr; // inside blob: next task of the chained block kernel (zeroed before every launch)
+    int n_cus = 256;
     int render_path = RT_PATH_AUTO, trace_path = RT_PATH_AUTO;
     int last_render_path = RT_PATH_EXACT;
 };
@@ -962,6 +1015,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
         total += (p.bytes + 255) & ~(size_t)255;
         total += 256; // a table may be empty; keep pointers distinct and in bounds
     }
+    const size_t counter_off = total; // the task counter of the chained block kernel
+    total += 256;
     std::vector<uint8_t> staging(total, 0);
     for (part &p : parts)
         if (p.bytes) memcpy(staging.data() + p.off, p.src, p.bytes);
@@ -1010,6 +1065,11 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     s->d_records = (uint32_t *)(b + parts[8].off);
     static_assert(offsetof(rt_record_table, face_user) == offsetof(rt_record_table, user_id) + sizeof tab.user_id, "one upload");
     s->d_rec_user = (int32_t *)(b + parts[9].off);
+    s->d_task_counter = (unsigned *)(b + counter_off);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
+    }
     s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights, {tab.run[0], tab.run[1], tab.run[2], tab.run[3]}, tab.n_runs, tab.n_spheres, 0u};
     for (int k = 0; k < tab.n_lights && k < 32; ++k)
         if ((tab.rec[tab.lights_base + k][7] & 15u) == RT_REC_LIGHT_RECT) s->layout.rect_lights |= 1u << k;
@@ -1096,7 +1156,9 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     A.n_chunks = (ns + A.chunk_samples - 1) / A.chunk_samples;
     A.sample_begin = p->sample_begin, A.n_samples = ns;
     A.sub_samples = p->sub_samples, A.max_depth = p->max_depth, A.seed = p->seed;
-    A.atomic_out = (accumulate || A.n_chunks > 1) ? 1 : 0;
+    // the chained block kernel (tools: RT_AMD_NO_CHAIN for the one-task-per-block form) always adds into the image
+    const bool chain = block_kernel && getenv("RT_AMD_NO_CHAIN") == nullptr;
+    A.atomic_out = (accumulate || A.n_chunks > 1 || chain) ? 1 : 0;
     const int64_t n_tasks = tiles * A.n_chunks;
     if (n_tasks > 0x7fffffff / 8) return rt_fail(RT_ERR_INVALID, "rt_render: %lld tasks; split the call", (long long)n_tasks);
     A.n_tasks = (int)n_tasks;
@@ -1115,11 +1177,19 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
             hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
         else
             hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
+    } else if (use_fast && block_kernel && chain) {
+        // as many blocks as the chip holds at once (eight per CU); each takes tasks from the counter until none is left
+        const dim3 g((unsigned)std::min<int64_t>(A.n_tasks, (int64_t)s->n_cus * RT_BLOCK_WAVES_PER_EU)), b(64 * BLOCK_WAVES);
+        RT_HIP(hipMemsetAsync(s->d_task_counter, 0, sizeof(unsigned), stream));
+        if (s->fast_flat)
+            hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+        else
+            hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
     } else if (use_fast && block_kernel) {
         if (s->fast_flat)
-            hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES, false>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
         else
-            hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES, false>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
     } else if (use_fast) {
         const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
         if (s->fast_textured && s->fast_flat)
