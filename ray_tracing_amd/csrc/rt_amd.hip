@@ -54,6 +54,7 @@ struct RenderArgs {
     int32_t atomic_out;    // 1: add into accum with atomics (several tasks per pixel or ACCUMULATE)
     int32_t n_tasks;
     int32_t stack_levels;  // per-lane fast path: inner levels of the tree = levels of the LDS stacks (dynamic LDS)
+    int32_t chain;         // per-lane fast path: 1 = a wave takes further tasks from the counter when its pool is empty
 };
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -717,20 +718,27 @@ template <bool TEX, bool BOX>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 __attribute__((amdgpu_waves_per_eu(RT_LANES_WAVES_PER_EU, RT_LANES_WAVES_PER_EU)))
 void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
-                                                                                 rtf::Layout Y, RenderArgs A, float *__restrict__ accum)
+                                                                                 rtf::Layout Y, RenderArgs A, float *__restrict__ accum, unsigned *__restrict__ next_task)
 {
     __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
+    __shared__ __align__(16) rt_camera lcam[WAVES_PER_BLOCK]; // read by the refill from LDS: the camera does not hold 24 SGPRs (one copy per wave: no barrier)
     extern __shared__ int bvh_stacks[]; // [WAVES_PER_BLOCK][A.stack_levels][64], sized by the launch
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (lane < (int)(sizeof(rt_camera) / 4)) reinterpret_cast<uint32_t *>(&lcam[wave])[lane] = reinterpret_cast<const uint32_t *>(&S.cam)[lane];
+    int task = blockIdx.x * WAVES_PER_BLOCK + wave; // A.chain: the first one; the counter hands out the ones after the grid's
     if (task >= A.n_tasks) return;
 
-    const int tile = task / A.n_chunks, chunk = task - tile * A.n_chunks;
-    const int tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
-    const int s0 = chunk * A.chunk_samples;
-    const int s1 = min(s0 + A.chunk_samples, A.n_samples);
-    const int total = 64 * (s1 - s0) * A.sub_samples;
+    int tile_x, tile_y, s0, s1, total;
+    // (A.chain: the lanes of paths that belong to the previous task carry their pixel's index in the image, with the sign bit)
+    auto open_task = [&](int tk) {
+        const int tile = tk / A.n_chunks, chunk = tk - tile * A.n_chunks;
+        tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
+        s0 = chunk * A.chunk_samples;
+        s1 = min(s0 + A.chunk_samples, A.n_samples);
+        total = tk < A.n_tasks ? 64 * (s1 - s0) * A.sub_samples : 0;
+    };
+    open_task(task);
     const float inv_nx = 1.0f / float(A.nx), inv_ny = 1.0f / float(A.ny);
 
     float *acc = tile_acc[wave];
@@ -760,12 +768,33 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                 V3 L;
                 if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
                     alive = false;
-                    if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
-                    if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
-                    if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[128 + pix], L.z);
+                    if (pix < 0) { // a path of the previous task: its tile has gone to the image already
+                        float *dst = accum + 4 * (size_t)(pix & 0x7fffffff);
+                        const float inv_sub = 1.0f / (float)A.sub_samples;
+                        if (L.x == L.x && L.x != 0.0f) atomicAdd(dst + 3, L.x * inv_sub);
+                        if (L.y == L.y && L.y != 0.0f) atomicAdd(dst + 2, L.y * inv_sub);
+                        if (L.z == L.z && L.z != 0.0f) atomicAdd(dst + 1, L.z * inv_sub);
+                    } else {
+                        if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
+                        if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
+                        if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[128 + pix], L.z);
+                    }
                 }
             }
             bool fresh = waiting & alive; // scattered: the new ray is in r
+            // The pool is empty: the tile goes to the image, the paths still on their way become the previous task's (they
+            // add to the image themselves), and the wave takes the next task, so its free lanes refill at once instead of
+            // idling until the longest of the last paths ends.  (Not while paths of the task before are still alive.)
+            if (A.chain && next >= total && task < A.n_tasks && !__any(alive & (pix < 0))) {
+                flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
+                acc[lane] = 0.0f, acc[64 + lane] = 0.0f, acc[128 + lane] = 0.0f;
+                if (alive) pix = (int)(0x80000000u | (uint32_t)((tile_y * 8 + (pix >> 3)) * A.nx + tile_x * 8 + (pix & 7)));
+                unsigned nt = 0u;
+                if (lane == 0) nt = atomicAdd(next_task, 1u);
+                task = (int)(__builtin_amdgcn_readfirstlane(nt) + gridDim.x * WAVES_PER_BLOCK);
+                open_task(task);
+                next = 0;
+            }
             const unsigned long long dead = __ballot(!alive);
             if (dead != 0ull && next < total) {
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
@@ -782,9 +811,10 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                         const int j = A.ny - 1 - row;
                         const float u = (float(col) + rng.next()) * inv_nx;
                         const float v = (float(j) + rng.next()) * inv_ny;
-                        const V3 disk = S.cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
+                        const rt_camera cam = lcam[wave];
+                        const V3 disk = cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
                         const float time01 = rng.next();
-                        r = rtf::camera_ray(S.cam, u, v, disk, time01);
+                        r = rtf::camera_ray(cam, u, v, disk, time01);
                         T = v3(1, 1, 1);
                         depth = 0;
                         alive = true;
@@ -1158,7 +1188,8 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     A.sub_samples = p->sub_samples, A.max_depth = p->max_depth, A.seed = p->seed;
     // the chained block kernel (tools: RT_AMD_NO_CHAIN for the one-task-per-block form) always adds into the image
     const bool chain = block_kernel && getenv("RT_AMD_NO_CHAIN") == nullptr;
-    A.atomic_out = (accumulate || A.n_chunks > 1 || chain) ? 1 : 0;
+    A.chain = (use_fast && s->lanes_ok && getenv("RT_AMD_NO_CHAIN") == nullptr) ? 1 : 0;
+    A.atomic_out = (accumulate || A.n_chunks > 1 || chain || A.chain) ? 1 : 0;
     const int64_t n_tasks = tiles * A.n_chunks;
     if (n_tasks > 0x7fffffff / 8) return rt_fail(RT_ERR_INVALID, "rt_render: %lld tasks; split the call", (long long)n_tasks);
     A.n_tasks = (int)n_tasks;
@@ -1166,17 +1197,21 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     RT_HIP(hipEventRecord(s->ev0, stream));
     if (use_fast && s->lanes_ok) {
-        const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
+        // chained: as many blocks as the chip holds at once (six waves per SIMD), each wave takes tasks from the counter
+        int64_t per_cu = RT_LANES_WAVES_PER_EU;
+        if (const char *e = getenv("RT_AMD_CHAIN_BLOCKS_PER_CU")) per_cu = atoll(e) > 0 ? atoll(e) : per_cu; // tuning aid
+        const dim3 g((unsigned)(A.chain ? std::min<int64_t>(blocks, (int64_t)s->n_cus * per_cu) : blocks)), b(64 * WAVES_PER_BLOCK);
+        if (A.chain) RT_HIP(hipMemsetAsync(s->d_task_counter, 0, sizeof(unsigned), stream));
         const size_t lds = (size_t)WAVES_PER_BLOCK * s->bvh_levels * 256; // the walks' stacks
         A.stack_levels = s->bvh_levels;
         if (s->fast_textured && s->lanes_boxes)
-            hipLaunchKernelGGL((render_fastlanes_kernel<true, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<true, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
         else if (s->fast_textured)
-            hipLaunchKernelGGL((render_fastlanes_kernel<true, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<true, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
         else if (s->lanes_boxes)
-            hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
         else
-            hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum);
+            hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
     } else if (use_fast && block_kernel && chain) {
         // as many blocks as the chip holds at once (eight per CU); each takes tasks from the counter until none is left
         const dim3 g((unsigned)std::min<int64_t>(A.n_tasks, (int64_t)s->n_cus * RT_BLOCK_WAVES_PER_EU)), b(64 * BLOCK_WAVES);
