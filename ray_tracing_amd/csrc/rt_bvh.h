@@ -3,7 +3,7 @@
  * The reference's tree (src/bvh.h:79-121: random axis, median split, boxes stored in the node itself, visited
  * left-right-both) is kept as it is for the exact path.  For the fast path the library builds a second tree over
  * the SAME primitives: world-space boxes (instance chains folded in), binned surface-area-heuristic splits, and
- * nodes that hold the boxes of BOTH children, so one 64-byte fetch decides two boxes and a leaf needs no node of
+ * nodes that hold the boxes of BOTH children, so one 32-byte fetch (half-float boxes) decides two boxes and a leaf needs no node of
  * its own.  The closest hit over a set of primitives does not depend on the tree that finds it (equal-distance
  * ties aside), so results are those of the reference's tree up to rounding; tests compare the two.
  * Internal to the library; not part of the ABI. */

@@ -4,7 +4,7 @@
 // Same algorithm and same random-draw order per primitive as the exact path, different machine mapping and
 // arithmetic, like rt_fast.hpp for small scenes:
 //   * every lane walks a tree on its own -- the library's tree over the same primitives (rt_bvh.h: world-space
-//     boxes, surface-area splits, both children's boxes in one 64-byte node), nearer child first, a box entered
+//     boxes, surface-area splits, both children's boxes in one 32-byte node), nearer child first, a box entered
 //     only if the ray reaches it before the best hit so far, pending children in a per-lane stack in LDS.
 //     The closest hit over a set of primitives does not depend on the tree or on the order of the visits
 //     (rt_device.hpp, world_hit_ordered, explains why); which of two hits at EQUAL distance wins may differ
