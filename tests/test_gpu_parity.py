@@ -155,6 +155,26 @@ def test_block_kernel_and_wave_kernel_trace_the_same_paths(cornell_gpu, monkeypa
     assert np.allclose(block[..., 1:].mean(axis=(0, 1)), wave[..., 1:].mean(axis=(0, 1)), rtol=1e-3)
 
 
+@pytest.mark.parametrize("scene,nx,ny,ns", [("cornell_box", 100, 60, 40), ("cornell_box", 16, 16, 3), ("random_spheres", 72, 40, 24),
+                                             ("cornell_box_volumes", 40, 40, 24)])
+def test_chained_tasks_trace_the_same_paths(scene, nx, ny, ns, monkeypatch):
+    """The fast kernels take task after task from a counter (a wave or block whose pool is empty flushes its tile and goes
+    on; the stragglers of the previous task add to the image themselves).  Paths are keyed by (pixel, sample), so the image
+    equals that of the one-task-per-wave form up to float summation order -- whatever the interleaving."""
+    hs = HostScene(scene, nx / ny)
+    sc = Scene(hs, 0)
+    sc.set_path(render=_capi.RT_PATH_FAST)
+    chained = gpu_render(sc, nx, ny, 0, ns, sub_samples=1, max_depth=50, seed=11)
+    again = gpu_render(sc, nx, ny, 0, ns, sub_samples=1, max_depth=50, seed=11)
+    monkeypatch.setenv("RT_AMD_NO_CHAIN", "1")
+    single = gpu_render(sc, nx, ny, 0, ns, sub_samples=1, max_depth=50, seed=11)
+    monkeypatch.delenv("RT_AMD_NO_CHAIN")
+    sc.close()
+    assert np.all(chained[..., 0] == ns) and np.all(single[..., 0] == ns)
+    assert np.allclose(chained, single, rtol=2e-5, atol=1e-5)
+    assert np.allclose(chained, again, rtol=2e-5, atol=1e-5)
+
+
 def test_generic_scan_with_box_records_matches_oracle(monkeypatch):
     """Scenes of more than 16 primitives keep their box records in the record table and are scanned by the generic loop
     (lanes that miss a box skip its subtree).  No built-in scene of that size fits the table, so the Cornell box is built
