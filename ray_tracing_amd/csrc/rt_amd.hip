@@ -898,7 +898,9 @@ struct rt_scene {
     rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids and 64 x 6 face ids (inside blob)
     int32_t *d_rec_user = nullptr;
-    unsigned *d_task_counter = nullptr; // inside blob: next task of the chained block kernel (zeroed before every launch)
+    unsigned *d_task_counters = nullptr; // inside blob: 64 task counters of the chained kernels, used in turn (each zeroed
+                                         // before its launch), so launches on different streams do not share one
+    unsigned launch_seq = 0;
     int n_cus = 256;
     int render_path = RT_PATH_AUTO, trace_path = RT_PATH_AUTO;
     int last_render_path = RT_PATH_EXACT;
@@ -1102,7 +1104,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     s->d_records = (uint32_t *)(b + parts[8].off);
     static_assert(offsetof(rt_record_table, face_user) == offsetof(rt_record_table, user_id) + sizeof tab.user_id, "one upload");
     s->d_rec_user = (int32_t *)(b + parts[9].off);
-    s->d_task_counter = (unsigned *)(b + counter_off);
+    s->d_task_counters = (unsigned *)(b + counter_off);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
@@ -1202,38 +1204,39 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     A.n_tasks = (int)n_tasks;
     if (A.atomic_out && !accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
     const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    unsigned *const d_task_counter = s->d_task_counters + (s->launch_seq++ & 63u);
     RT_HIP(hipEventRecord(s->ev0, stream));
     if (use_fast && s->lanes_ok) {
         // chained: as many blocks as the chip holds at once (six waves per SIMD), each wave takes tasks from the counter
         int64_t per_cu = RT_LANES_WAVES_PER_EU;
         if (const char *e = getenv("RT_AMD_CHAIN_BLOCKS_PER_CU")) per_cu = atoll(e) > 0 ? atoll(e) : per_cu; // tuning aid
         const dim3 g((unsigned)(A.chain ? std::min<int64_t>(blocks, (int64_t)s->n_cus * per_cu) : blocks)), b(64 * WAVES_PER_BLOCK);
-        if (A.chain) RT_HIP(hipMemsetAsync(s->d_task_counter, 0, sizeof(unsigned), stream));
+        if (A.chain) RT_HIP(hipMemsetAsync(d_task_counter, 0, sizeof(unsigned), stream));
         const size_t lds = (size_t)WAVES_PER_BLOCK * s->bvh_levels * 256; // the walks' stacks
         A.stack_levels = s->bvh_levels;
         A.node_steps = s->bvh_levels > 20 ? 4 : 2;
         if (const char *e = getenv("RT_AMD_NODE_STEPS")) A.node_steps = atoi(e) > 0 ? atoi(e) : A.node_steps; // tuning aid
         if (s->fast_textured && s->lanes_boxes)
-            hipLaunchKernelGGL((render_fastlanes_kernel<true, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+            hipLaunchKernelGGL((render_fastlanes_kernel<true, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
         else if (s->fast_textured)
-            hipLaunchKernelGGL((render_fastlanes_kernel<true, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+            hipLaunchKernelGGL((render_fastlanes_kernel<true, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
         else if (s->lanes_boxes)
-            hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+            hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
         else
-            hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+            hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
     } else if (use_fast && block_kernel && chain) {
         // as many blocks as the chip holds at once (eight per CU); each takes tasks from the counter until none is left
         const dim3 g((unsigned)std::min<int64_t>(A.n_tasks, (int64_t)s->n_cus * RT_BLOCK_WAVES_PER_EU)), b(64 * BLOCK_WAVES);
-        RT_HIP(hipMemsetAsync(s->d_task_counter, 0, sizeof(unsigned), stream));
+        RT_HIP(hipMemsetAsync(d_task_counter, 0, sizeof(unsigned), stream));
         if (s->fast_flat)
-            hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+            hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
         else
-            hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+            hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
     } else if (use_fast && block_kernel) {
         if (s->fast_flat)
-            hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES, false>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+            hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES, false>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
         else
-            hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES, false>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum, s->d_task_counter);
+            hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES, false>), dim3(A.n_tasks), dim3(64 * BLOCK_WAVES), 0, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
     } else if (use_fast) {
         const dim3 g(blocks), b(64 * WAVES_PER_BLOCK);
         if (s->fast_textured && s->fast_flat)
