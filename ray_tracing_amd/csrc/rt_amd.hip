@@ -55,7 +55,6 @@ struct RenderArgs {
     int32_t n_tasks;
     int32_t stack_levels;  // per-lane fast path: inner levels of the tree = levels of the LDS stacks (dynamic LDS)
     int32_t chain;         // per-lane fast path: 1 = a wave takes further tasks from the counter when its pool is empty
-    int32_t node_steps;    // per-lane fast path: node steps per turn of the loop
 };
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -712,15 +711,15 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 16
 #endif
-// Node steps between two looks at who waits for a leaf test or for shading (RenderArgs.node_steps; the looks cost a fifth of
-// a node step).  1 / 2 / 3 / 4 steps: random spheres 6.1 / 6.4 / 6.3 / 6.2, Next-Week final 1.63 / 1.75 / 1.75 / 1.66, 1M spheres
+// Node steps between two looks at who waits for a leaf test or for shading (template parameter STEPS; the looks cost a fifth
+// of a node step).  1 / 2 / 3 / 4 steps: random spheres 6.1 / 6.4 / 6.3 / 6.2, Next-Week final 1.63 / 1.75 / 1.75 / 1.66, 1M spheres
 // 1.04 / 1.09 / 1.15 / 1.18 Gpaths/s: two, and four for deep trees.
 // Six waves per SIMD is what the LDS stacks allow (six blocks per CU, rt_bvh.h); left alone the kernels take 89 / 101 VGPRs
 // (five / four waves).  Held to 80: random spheres +10 %, Next-Week final +12 %, 1M spheres +4 %.
 #ifndef RT_LANES_WAVES_PER_EU
 #define RT_LANES_WAVES_PER_EU 6
 #endif
-template <bool TEX, bool BOX>
+template <bool TEX, bool BOX, int STEPS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 __attribute__((amdgpu_waves_per_eu(RT_LANES_WAVES_PER_EU, RT_LANES_WAVES_PER_EU)))
 void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
@@ -836,7 +835,8 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
             }
         }
         // ---- the walks ------------------------------------------------------------------------------
-        for (int step = 0; step < A.node_steps; ++step)
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step)
             if (w.cur >= 0) rtf::walk_node(S, w, 0.001f, stack);
         const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
         if (__popcll(__ballot(at_leaf)) >= RT_LEAF_BATCH || !__any(w.cur >= 0)) {
@@ -1214,16 +1214,18 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
         if (A.chain) RT_HIP(hipMemsetAsync(d_task_counter, 0, sizeof(unsigned), stream));
         const size_t lds = (size_t)WAVES_PER_BLOCK * s->bvh_levels * 256; // the walks' stacks
         A.stack_levels = s->bvh_levels;
-        A.node_steps = s->bvh_levels > 20 ? 4 : 2;
-        if (const char *e = getenv("RT_AMD_NODE_STEPS")) A.node_steps = atoi(e) > 0 ? atoi(e) : A.node_steps; // tuning aid
-        if (s->fast_textured && s->lanes_boxes)
-            hipLaunchKernelGGL((render_fastlanes_kernel<true, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
-        else if (s->fast_textured)
-            hipLaunchKernelGGL((render_fastlanes_kernel<true, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
-        else if (s->lanes_boxes)
-            hipLaunchKernelGGL((render_fastlanes_kernel<false, true>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
-        else
-            hipLaunchKernelGGL((render_fastlanes_kernel<false, false>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
+        int steps = s->bvh_levels > 20 ? 4 : 2;
+        if (const char *e = getenv("RT_AMD_NODE_STEPS")) steps = atoi(e) == 4 ? 4 : atoi(e) == 2 ? 2 : steps; // tuning aid
+#define RT_LAUNCH_LANES(TEX, BOX, STEPS) \
+    hipLaunchKernelGGL((render_fastlanes_kernel<TEX, BOX, STEPS>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter)
+#define RT_LAUNCH_LANES_STEPS(TEX, BOX) \
+    do { if (steps == 4) RT_LAUNCH_LANES(TEX, BOX, 4); else RT_LAUNCH_LANES(TEX, BOX, 2); } while (0)
+        if (s->fast_textured && s->lanes_boxes) RT_LAUNCH_LANES_STEPS(true, true);
+        else if (s->fast_textured) RT_LAUNCH_LANES_STEPS(true, false);
+        else if (s->lanes_boxes) RT_LAUNCH_LANES_STEPS(false, true);
+        else RT_LAUNCH_LANES_STEPS(false, false);
+#undef RT_LAUNCH_LANES_STEPS
+#undef RT_LAUNCH_LANES
     } else if (use_fast && block_kernel && chain) {
         // as many blocks as the chip holds at once (eight per CU); each takes tasks from the counter until none is left
         const dim3 g((unsigned)std::min<int64_t>(A.n_tasks, (int64_t)s->n_cus * RT_BLOCK_WAVES_PER_EU)), b(64 * BLOCK_WAVES);
