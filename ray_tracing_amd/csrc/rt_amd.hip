@@ -1169,8 +1169,8 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     A.tiles_x = (p->nx + tile_w - 1) / tile_w, A.tiles_y = (p->ny + tile_h - 1) / tile_h;
     const int64_t tiles = (int64_t)A.tiles_x * A.tiles_y;
     // Tiles differ a lot in cost (glass sphere vs. open front), so the image is cut into many more
-    // tasks than the chip holds waves (7168 at 7 waves/SIMD) and the hardware dispatcher balances
-    // them; measured on Cornell 1024x1024x1024spp: 16 Ki tasks 5.1, 128 Ki 6.9, 256 Ki 7.0, 1 Mi 6.3
+    // tasks than the chip holds waves (8192 at 8 waves/SIMD) and the dispatcher -- or, for the chained
+    // kernels, the task counter -- balances them; measured on Cornell 1024x1024x1024spp: 16 Ki tasks 5.1, 128 Ki 6.9, 256 Ki 7.0, 1 Mi 6.3
     // Gpaths/s.  Each task keeps at least 16 paths per lane so that the drain of its pool (a few
     // long paths finishing alone) stays small beside its body -- 8 when that leaves too few tasks
     // (16-spp renders, 16 / 8 / 4 paths per lane: Next-Week final 0.71 / 0.89 / 0.96, random spheres
