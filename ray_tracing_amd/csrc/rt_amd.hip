@@ -1171,20 +1171,25 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     // Tiles differ a lot in cost (glass sphere vs. open front), so the image is cut into many more
     // tasks than the chip holds waves (8192 at 8 waves/SIMD) and the dispatcher -- or, for the chained
     // kernels, the task counter -- balances them; measured on Cornell 1024x1024x1024spp: 16 Ki tasks 5.1, 128 Ki 6.9, 256 Ki 7.0, 1 Mi 6.3
-    // Gpaths/s.  Each task keeps at least 16 paths per lane so that the drain of its pool (a few
-    // long paths finishing alone) stays small beside its body -- 8 when that leaves too few tasks
-    // (16-spp renders, 16 / 8 / 4 paths per lane: Next-Week final 0.71 / 0.89 / 0.96, random spheres
-    // 3.5 / 4.3 / 4.5, Cornell 8.6 / 9.3 / 8.3 Gpaths/s; with enough tasks 16 is the better: random
-    // spheres at 64 spp 6.4 against 5.9).
+    // Gpaths/s (one task per wave, early in the round).  Each task keeps at least 8 paths per lane -- 4 when that
+    // leaves too few tasks (16 / 8 for the kernels that do not chain tasks).  Before tasks were chained the drain of a task's pool (a few long paths finishing alone) made
+    // 16 / 8 the better rule; chained, 32 / 16 / 8 / 4 paths per lane give Cornell 128 spp 10.2 / 9.7 / 9.6 / 9.6 ms,
+    // random spheres 64 spp 6.5 / 6.1 / 6.7 / 6.5, Next-Week final 1.61 / 1.74 / 1.79 / 1.67, 1M spheres 16 spp
+    // 1.06 / 1.16 / 1.19 / 1.06 Gpaths/s.
     int64_t target_tasks = 262144;
     if (const char *e = getenv("RT_AMD_TARGET_TASKS")) target_tasks = atoll(e) > 0 ? atoll(e) : target_tasks; // tuning aid
     target_tasks /= waves_per_task;
     int64_t want_chunks = (target_tasks + tiles - 1) / tiles;
     const int64_t all_paths = (int64_t)ns * p->sub_samples;
-    const int64_t want = want_chunks, cap16 = (all_paths + 15) / 16, cap8 = (all_paths + 7) / 8;
-    if (want_chunks > cap16) want_chunks = cap16;
-    const int64_t few = 49152 / waves_per_task; // below this many tasks the end of the launch shows: go down to 8 paths per lane
-    if (tiles * want_chunks < few) want_chunks = std::min(std::min((few + tiles - 1) / tiles, cap8), want);
+    // chained kernels (tools: RT_AMD_NO_CHAIN=1 for the one-task-per-wave / per-block forms)
+    const bool chain = block_kernel && getenv("RT_AMD_NO_CHAIN") == nullptr;
+    A.chain = (use_fast && s->lanes_ok && getenv("RT_AMD_NO_CHAIN") == nullptr) ? 1 : 0;
+    int64_t hi_paths = (chain || A.chain) ? 8 : 16, lo_paths = hi_paths / 2;
+    if (const char *e = getenv("RT_AMD_PATHS_PER_LANE")) { hi_paths = atoll(e) > 0 ? atoll(e) : hi_paths; lo_paths = std::max<int64_t>(1, hi_paths / 2); } // tuning aid
+    const int64_t want = want_chunks, cap_hi = (all_paths + hi_paths - 1) / hi_paths, cap_lo = (all_paths + lo_paths - 1) / lo_paths;
+    if (want_chunks > cap_hi) want_chunks = cap_hi;
+    const int64_t few = 49152 / waves_per_task; // below this many tasks the end of the launch shows: the lower bound on paths per lane
+    if (tiles * want_chunks < few) want_chunks = std::min(std::min((few + tiles - 1) / tiles, cap_lo), want);
     if (want_chunks > ns) want_chunks = ns;
     if (want_chunks < 1) want_chunks = 1;
     {   // a task's pool is counted in 32 bits (up to 512 items per sample in the block kernel)
@@ -1195,10 +1200,7 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     A.n_chunks = (ns + A.chunk_samples - 1) / A.chunk_samples;
     A.sample_begin = p->sample_begin, A.n_samples = ns;
     A.sub_samples = p->sub_samples, A.max_depth = p->max_depth, A.seed = p->seed;
-    // the chained block kernel (tools: RT_AMD_NO_CHAIN for the one-task-per-block form) always adds into the image
-    const bool chain = block_kernel && getenv("RT_AMD_NO_CHAIN") == nullptr;
-    A.chain = (use_fast && s->lanes_ok && getenv("RT_AMD_NO_CHAIN") == nullptr) ? 1 : 0;
-    A.atomic_out = (accumulate || A.n_chunks > 1 || chain || A.chain) ? 1 : 0;
+    A.atomic_out = (accumulate || A.n_chunks > 1 || chain || A.chain) ? 1 : 0; // the chained kernels always add into the image
     const int64_t n_tasks = tiles * A.n_chunks;
     if (n_tasks > 0x7fffffff / 8) return rt_fail(RT_ERR_INVALID, "rt_render: %lld tasks; split the call", (long long)n_tasks);
     A.n_tasks = (int)n_tasks;
