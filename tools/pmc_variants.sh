@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for so in $root/ray_tracing_amd/build_var/librt_*.so; do
   tag=$(basename $so .so)
   export RT_AMD_LIB=$so
-  timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $out/$tag -- python3 $root/tools/scene_bench.py $job > $out/$tag.log 2>&1 || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $out/$tag -- python3 $root/tools/scene_bench.py $job > $out/$tag.log 2>&1 || exit 1
   echo "== $tag"; grep Mpaths $out/$tag.log
   python3 - $out/$tag <<'PY'
 import csv,glob,sys,os
