@@ -233,6 +233,17 @@ typedef struct rt_hit {
 int rt_trace_rays(rt_scene* scene, int32_t n, const float* h_rays, float t_min, float t_max,
                   uint32_t seed, rt_hit* h_hits_out);
 
+/* rt_trace_rays for callers that cannot allocate (a tight query loop, a harness that forbids hipMalloc):
+ * same arguments, same results, but the device staging of rays and hits lives in a static device array of the
+ * library (RT_TRACE_NOALLOC_MAX_RAYS x 76 bytes = 4.75 MiB, held by every GPU the library runs on until the
+ * process ends) instead of two hipMalloc'ed buffers per call.  Calls no hipMalloc / hipFree.  n above
+ * RT_TRACE_NOALLOC_MAX_RAYS is rejected with RT_ERR_INVALID.  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (two host threads, two scenes on the same device) race; serialise them.
+ * No counterpart in the reference (it has no device and no staging); it exists for callers that cannot allocate. */
+#define RT_TRACE_NOALLOC_MAX_RAYS 65536
+int rt_trace_rays_noalloc(rt_scene* scene, int32_t n, const float* h_rays, float t_min, float t_max,
+                          uint32_t seed, rt_hit* h_hits_out);
+
 /* ------------------------------------------------------------------ */
 /* Execution paths                                                      */
 /* ------------------------------------------------------------------ */

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "librt_amd.so")
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM = -1, -2, -3, -4
 RT_RENDER_ACCUMULATE = 1
+RT_TRACE_NOALLOC_MAX_RAYS = 65536
 RT_OPT_RENDER_PATH, RT_OPT_TRACE_PATH = 1, 2
 RT_PATH_AUTO, RT_PATH_EXACT, RT_PATH_FAST = 0, 1, 2
 RT_INFO_FAST_PATH_AVAILABLE, RT_INFO_LAST_RENDER_PATH, RT_INFO_RECORDS = 1, 2, 3
@@ -99,6 +100,7 @@ PROTOTYPES = {
     "rt_render_to_host": (C.c_int, [C.c_void_p, C.POINTER(rt_render_params), C.c_void_p, C.c_void_p]),
     "rt_camera_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
+    "rt_trace_rays_noalloc": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_int, []),
     "rt_device_count": (C.c_int, []),

@@ -133,9 +133,12 @@ HIT_DTYPE = np.dtype([("prim_id", "<i4"), ("material", "<i4"), ("t", "<f4"), ("u
 assert HIT_DTYPE.itemsize == C.sizeof(rt_hit)
 
 
-def trace_rays(scene, rays, t_min=0.001, t_max=3.4028234663852886e38, seed=0):
+def trace_rays(scene, rays, t_min=0.001, t_max=3.4028234663852886e38, seed=0, noalloc=False):
+    """rt_trace_rays, or rt_trace_rays_noalloc (static device staging, at most RT_TRACE_NOALLOC_MAX_RAYS rays)."""
     rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
     hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
-    _check(_capi.load().rt_trace_rays(scene._s, rays.shape[0], rays.ctypes.data_as(C.c_void_p), C.c_float(t_min),
-                                      C.c_float(t_max), seed, hits.ctypes.data_as(C.c_void_p)), "rt_trace_rays")
+    lib = _capi.load()
+    fn, name = (lib.rt_trace_rays_noalloc, "rt_trace_rays_noalloc") if noalloc else (lib.rt_trace_rays, "rt_trace_rays")
+    _check(fn(scene._s, rays.shape[0], rays.ctypes.data_as(C.c_void_p), C.c_float(t_min), C.c_float(t_max), seed,
+              hits.ctypes.data_as(C.c_void_p)), name)
     return hits

@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -901,6 +902,7 @@ struct rt_scene {
     unsigned *d_task_counters = nullptr; // inside blob: 64 task counters of the chained kernels, used in turn (each zeroed
                                          // before its launch), so launches on different streams do not share one
     unsigned launch_seq = 0;
+    unsigned char *scratch = nullptr; // this device's copy of the static staging area (rt_trace_rays_noalloc)
     int n_cus = 256;
     int render_path = RT_PATH_AUTO, trace_path = RT_PATH_AUTO;
     int last_render_path = RT_PATH_EXACT;
@@ -911,6 +913,38 @@ struct rt_scene {
         hipError_t e_ = (call);                                                                                        \
         if (e_ != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "%s: %s", #call, hipGetErrorString(e_));                \
     } while (0)
+
+// ---------------------------------------------------------------------------
+// rt_trace_rays_noalloc: rt_trace_rays for callers that cannot allocate.  The device staging of the rays and of the
+// hits (what rt_trace_rays takes from hipMalloc on every call) lives in `scratch`, a file-scope device array that every
+// GPU the library runs on holds until the process ends.  In host code the NAME `scratch` is a stand-in, not a device
+// address: the address on each device comes from hipGetSymbolAddress, asked once per device with that device current
+// (rt_scene_create does it, so the entry point itself only looks it up), and only that pointer is ever handed to a
+// copy or a kernel.
+// ---------------------------------------------------------------------------
+constexpr size_t NOALLOC_RAYS_BYTES = (size_t)RT_TRACE_NOALLOC_MAX_RAYS * 28;
+constexpr size_t NOALLOC_HITS_OFFSET = (NOALLOC_RAYS_BYTES + 255) & ~(size_t)255;
+constexpr size_t NOALLOC_BYTES = NOALLOC_HITS_OFFSET + (size_t)RT_TRACE_NOALLOC_MAX_RAYS * sizeof(rt_hit);
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES]; // 4.75 MiB per GPU
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_scratch_mutex;
+static void *g_scratch_ptr[NOALLOC_MAX_DEVICES]; // [device]: that device's copy of `scratch`
+
+// `device` must be current.  Asks the runtime once per device.
+static int scratch_of_device(int device, void **out)
+{
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return rt_fail(RT_ERR_INVALID, "device %d: the static staging area serves devices 0..%d", device, NOALLOC_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        RT_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return rt_fail(RT_ERR_NO_DEVICE, "hipGetSymbolAddress(scratch) returned no address on device %d", device);
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
 
 static int validate(const rt_scene_desc *d)
 {
@@ -1013,6 +1047,9 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     if (ndev < 0) return ndev;
     if (device < 0 || device >= ndev) return rt_fail(RT_ERR_NO_DEVICE, "rt_scene_create: device %d of %d", device, ndev);
     RT_HIP(hipSetDevice(device));
+    void *scratch_ptr = nullptr; // this device's copy of the static staging area, asked for once per device
+    st = scratch_of_device(device, &scratch_ptr);
+    if (st != RT_OK) return st;
 
     // one blob, every table 256-byte aligned
     struct part {
@@ -1063,6 +1100,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     rt_scene *s = new (std::nothrow) rt_scene;
     if (!s) return rt_fail(RT_ERR_NOMEM, "rt_scene_create: out of host memory");
     s->device = device;
+    s->scratch = static_cast<unsigned char *>(scratch_ptr);
     hipError_t e = hipMalloc(&s->blob, total);
     if (e != hipSuccess) {
         delete s;
@@ -1330,6 +1368,21 @@ extern "C" int rt_camera_rays(rt_scene *s, int32_t n, const float *h_st, const f
     return RT_OK;
 }
 
+// the closest-hit kernel the scene's trace option selects, on the null stream (shared by the two entry points below)
+static hipError_t launch_trace(rt_scene *s, int32_t n, const float *d_rays, float t_min, float t_max, uint32_t seed, rt_hit *d_hits)
+{
+    if (s->trace_path == RT_PATH_FAST && s->lanes_ok)
+        hipLaunchKernelGGL(trace_fastlanes_kernel, dim3((n + 255) / 256), dim3(256), (size_t)4 * s->bvh_levels * 256, nullptr, s->dev, n, d_rays, t_min, t_max, seed, s->bvh_levels, d_hits);
+    else if (s->trace_path == RT_PATH_FAST)
+        hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
+                           d_rays, t_min, t_max, d_hits);
+    else if (s->dev.n_entries > RT_UNIFORM_WALK_MAX)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
+    return hipGetLastError();
+}
+
 extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float t_min, float t_max, uint32_t seed, rt_hit *h_hits)
 {
     if (!s || n < 0 || (n > 0 && (!h_rays || !h_hits))) return rt_fail(RT_ERR_INVALID, "rt_trace_rays: bad argument");
@@ -1343,22 +1396,32 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
     RT_HIP(hipMalloc(&d_rays, 28 * N));
     hipError_t e = hipMalloc(&d_hits, sizeof(rt_hit) * N);
     if (e == hipSuccess) e = hipMemcpy(d_rays, h_rays, 28 * N, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        if (s->trace_path == RT_PATH_FAST && s->lanes_ok)
-            hipLaunchKernelGGL(trace_fastlanes_kernel, dim3((n + 255) / 256), dim3(256), (size_t)4 * s->bvh_levels * 256, nullptr, s->dev, n, d_rays, t_min, t_max, seed, s->bvh_levels, d_hits);
-        else if (s->trace_path == RT_PATH_FAST)
-            hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
-                               d_rays, t_min, t_max, d_hits);
-        else if (s->dev.n_entries > RT_UNIFORM_WALK_MAX)
-            hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
-        else
-            hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);
-        e = hipGetLastError();
-    }
+    if (e == hipSuccess) e = launch_trace(s, n, d_rays, t_min, t_max, seed, d_hits);
     if (e == hipSuccess) e = hipMemcpy(h_hits, d_hits, sizeof(rt_hit) * N, hipMemcpyDeviceToHost);
     (void)hipFree(d_rays);
     if (d_hits) (void)hipFree(d_hits);
     if (e != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "rt_trace_rays: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+extern "C" int rt_trace_rays_noalloc(rt_scene *s, int32_t n, const float *h_rays, float t_min, float t_max, uint32_t seed, rt_hit *h_hits)
+{
+    if (!s || n < 0 || (n > 0 && (!h_rays || !h_hits))) return rt_fail(RT_ERR_INVALID, "rt_trace_rays_noalloc: bad argument");
+    if (n > RT_TRACE_NOALLOC_MAX_RAYS)
+        return rt_fail(RT_ERR_INVALID, "rt_trace_rays_noalloc: %d rays, the static staging area holds %d; split the batch or use rt_trace_rays", n,
+                       RT_TRACE_NOALLOC_MAX_RAYS);
+    if (n == 0) return RT_OK;
+    if (s->trace_path == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
+        return rt_fail(RT_ERR_UNSUPPORTED, "rt_trace_rays_noalloc: the fast path was requested but cannot run this scene (%s; and no ordered walk)", s->fast_why);
+    if (!s->scratch) return rt_fail(RT_ERR_NO_DEVICE, "rt_trace_rays_noalloc: the scene holds no address of the staging area");
+    RT_HIP(hipSetDevice(s->device));
+    const size_t N = (size_t)n;
+    float *d_rays = reinterpret_cast<float *>(s->scratch);
+    rt_hit *d_hits = reinterpret_cast<rt_hit *>(s->scratch + NOALLOC_HITS_OFFSET);
+    // nothing has to start at zero: the kernel reads rays [0, n) -- all just written -- and writes every hit [0, n) it returns
+    RT_HIP(hipMemcpy(d_rays, h_rays, 28 * N, hipMemcpyHostToDevice));
+    RT_HIP(launch_trace(s, n, d_rays, t_min, t_max, seed, d_hits));
+    RT_HIP(hipMemcpy(h_hits, d_hits, sizeof(rt_hit) * N, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
