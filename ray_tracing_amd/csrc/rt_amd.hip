@@ -665,11 +665,17 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     if (CHAIN) flush(true);
 }
 
-// world->hit() on the record table (what render_fast_kernel's bounces see)
+// world->hit() on the record table: the SAME scan the render kernels of this scene run (FLAT: the run scan over the
+// block's LDS copy of the table, as render_fast_block_kernel; else the generic one), so what rt_trace_rays reports on
+// RT_PATH_FAST is what the bounces of rt_render see
+template <bool FLAT>
 __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restrict__ recs, const int32_t *__restrict__ rec_user,
                                                          rtf::Layout Y, int n, const float *__restrict__ rays, float t_min,
                                                          float t_max, rt_hit *__restrict__ out)
 {
+    __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
+    for (int k = threadIdx.x; k < (RT_REC_MAX + 1) * 8; k += 256) lrecs[k] = recs[k];
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     rtf::Regs R;
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
     float t;
     int rec;
-    rtf::scan<false>(recs, nullptr, Y, r, t_min, t_max, alive, t, rec); // the general form also walks flat streams
+    rtf::scan<FLAT>(recs, lrecs, Y, r, t_min, t_max, alive, t, rec);
     rtf::Surface sf;
     rtf::build_surface(R, Y, r, t, rec, sf);
     const uint32_t kw = rtf::sh_u(R.d[7], rec < 0 ? 0 : rec);
@@ -1373,8 +1379,11 @@ static hipError_t launch_trace(rt_scene *s, int32_t n, const float *d_rays, floa
 {
     if (s->trace_path == RT_PATH_FAST && s->lanes_ok)
         hipLaunchKernelGGL(trace_fastlanes_kernel, dim3((n + 255) / 256), dim3(256), (size_t)4 * s->bvh_levels * 256, nullptr, s->dev, n, d_rays, t_min, t_max, seed, s->bvh_levels, d_hits);
+    else if (s->trace_path == RT_PATH_FAST && s->fast_flat)
+        hipLaunchKernelGGL(trace_fast_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
+                           d_rays, t_min, t_max, d_hits);
     else if (s->trace_path == RT_PATH_FAST)
-        hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
+        hipLaunchKernelGGL(trace_fast_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_records, s->d_rec_user, s->layout, n,
                            d_rays, t_min, t_max, d_hits);
     else if (s->dev.n_entries > RT_UNIFORM_WALK_MAX)
         hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->dev, n, d_rays, t_min, t_max, seed, d_hits);

@@ -73,6 +73,36 @@ struct Layout { // wave-uniform description of the table
     uint32_t rect_lights; // bit k: member k of the important list is a rect (the first 32 members)
 };
 
+// Arithmetic that decides WHICH primitive is hit (north_star check 1: ids equal to the reference's hitable::hit).
+// The plane distance t = (k - o) / d of a rect (src/plane.h:11,49,111) is the reference's correctly rounded quotient,
+// at the price of two FMAs instead of an IEEE division: with y = 1/d refined once per ray (Newton step on v_rcp_f32),
+// q = n*y, r = fma(-q, d, n) is the exact remainder and fma(r, y, q) rounds to the quotient (Markstein); the in-plane
+// point is o + t*d with the product and the sum rounded one after the other, as g++ compiles it (no contraction).
+// -DRT_FAST_APPROX_T gives the round-1 arithmetic back (v_rcp and FMA; t within an ulp or two): a development switch
+// that prices the difference (tools/build_variant.sh).
+RTF_DEV float mul_rn(float a, float b) { return __fmul_rn(a, b); } // never contracted into an FMA
+RTF_DEV float add_rn(float a, float b) { return __fadd_rn(a, b); }
+RTF_DEV float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+RTF_DEV float refined_rcp(float d)
+{
+    const float y = rcp(d);
+#ifdef RT_FAST_APPROX_T
+    return y;
+#else
+    return fmaf(fmaf(-d, y, 1.0f), y, y); // d = 0: NaN, and a NaN t is never a hit
+#endif
+}
+// n / d, correctly rounded, from y = refined_rcp(d)
+RTF_DEV float div_rn(float n, float d, float y)
+{
+    const float q = n * y;
+#ifdef RT_FAST_APPROX_T
+    return q;
+#else
+    return fmaf(fmaf(-q, d, n), y, q);
+#endif
+}
+
 // the ray in the space of the current chain, with what the slab and rect tests need
 struct LocalRay {
     V3 o, d, inv;
@@ -80,7 +110,7 @@ struct LocalRay {
 RTF_DEV void set_local(LocalRay &l, V3 o, V3 d)
 {
     l.o = o, l.d = d;
-    l.inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
+    l.inv = v3(refined_rcp(d.x), refined_rcp(d.y), refined_rcp(d.z));
 }
 
 // One stream record in SGPRs.  The scan reads the record table with wave-uniform scalar loads
@@ -109,9 +139,9 @@ RTF_DEV void apply_chain(const uint32_t *__restrict__ recs, uint32_t chain_bits,
         const float a = sf(x, 0), b = sf(x, 1);
         if ((x.d[7] & 15u) == RT_REC_XFORM_T) {
             o = v3(o.x - a, o.y - b, o.z - sf(x, 2));
-        } else { // a = sin, b = cos
-            const float ox = b * o.x - a * o.z, oz = a * o.x + b * o.z;
-            const float dx = b * d.x - a * d.z, dz = a * d.x + b * d.z;
+        } else { // a = sin, b = cos; products and sums rounded one by one, as the reference's (src/transforms.h:107-110)
+            const float ox = sub_rn(mul_rn(b, o.x), mul_rn(a, o.z)), oz = add_rn(mul_rn(a, o.x), mul_rn(b, o.z));
+            const float dx = sub_rn(mul_rn(b, d.x), mul_rn(a, d.z)), dz = add_rn(mul_rn(a, d.x), mul_rn(b, d.z));
             o.x = ox, o.z = oz, d.x = dx, d.z = dz;
         }
     }
@@ -129,11 +159,15 @@ RTF_DEV void apply_chain(const uint32_t *__restrict__ recs, uint32_t chain_bits,
 // ---------------------------------------------------------------------------
 // One rect record against the ray of its chain.  Straight-line code per axis (the axis is
 // wave-uniform); bitwise & on purpose: && would make hipcc branch around every comparison.
-RTF_DEV bool rect_in(const SRec &c, float ok, float ik, float oa, float da, float ob, float db, float t_min, float bound,
+RTF_DEV bool rect_in(const SRec &c, float ok, float dk, float ik, float oa, float da, float ob, float db, float t_min, float bound,
                      float &t)
 {
-    t = (sf(c, 4) - ok) * ik;
+    t = div_rn(sf(c, 4) - ok, dk, ik);
+#ifdef RT_FAST_APPROX_T
     const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
+#else
+    const float a = add_rn(oa, mul_rn(t, da)), b = add_rn(ob, mul_rn(t, db));
+#endif
     return (t >= t_min) & (t <= bound) & (a >= sf(c, 0)) & (a <= sf(c, 1)) & (b >= sf(c, 2)) & (b <= sf(c, 3));
 }
 
@@ -143,16 +177,30 @@ RTF_DEV bool rect_in(const SRec &c, float ok, float ik, float oa, float da, floa
 // (35 scalar against 13 vector instructions per record).  Here the six comparisons narrow EXEC one after the other
 // (v_cmpx), the two moves run under what is left, and EXEC is restored: 12 vector and 2 scalar instructions.
 // Comparisons in positive form, so a NaN is never a hit.
+#ifdef RT_FAST_APPROX_T
+#define RTF_RECT_T_AND_POINT                                                                                             \
+    "v_sub_f32 %[t], %[k], %[ok]\n\t"                                                                                    \
+    "v_mul_f32 %[t], %[t], %[ik]\n\t"                                                                                    \
+    "v_fma_f32 %[a], %[t], %[da], %[oa]\n\t"                                                                             \
+    "v_fma_f32 %[b], %[t], %[db], %[ob]\n\t"
+#else // t = (k - o) / d correctly rounded (div_rn), the point with product and sum rounded one after the other
+#define RTF_RECT_T_AND_POINT                                                                                             \
+    "v_sub_f32 %[t], %[k], %[ok]\n\t"                                                                                    \
+    "v_mul_f32 %[a], %[t], %[ik]\n\t"                                                                                    \
+    "v_fma_f32 %[b], -%[a], %[dk], %[t]\n\t"                                                                             \
+    "v_fma_f32 %[t], %[b], %[ik], %[a]\n\t"                                                                              \
+    "v_mul_f32 %[a], %[t], %[da]\n\t"                                                                                    \
+    "v_add_f32 %[a], %[a], %[oa]\n\t"                                                                                    \
+    "v_mul_f32 %[b], %[t], %[db]\n\t"                                                                                    \
+    "v_add_f32 %[b], %[b], %[ob]\n\t"
+#endif
 #define RTF_RECT_UPDATE(NAME, RC)                                                                                        \
-    RTF_DEV void NAME(float k, float a0, float a1, float b0, float b1, float t_min, int index, float ok, float ik, float oa, \
-                      float da, float ob, float db, float &best_t, int &best_rec)                                         \
+    RTF_DEV void NAME(float k, float a0, float a1, float b0, float b1, float t_min, int index, float ok, float dk, float ik, \
+                      float oa, float da, float ob, float db, float &best_t, int &best_rec)                               \
     {                                                                                                                    \
         float t, a, b;                                                                                                   \
         unsigned long long saved;                                                                                        \
-        asm volatile("v_sub_f32 %[t], %[k], %[ok]\n\t"                                                                   \
-                     "v_mul_f32 %[t], %[t], %[ik]\n\t"                                                                   \
-                     "v_fma_f32 %[a], %[t], %[da], %[oa]\n\t"                                                            \
-                     "v_fma_f32 %[b], %[t], %[db], %[ob]\n\t"                                                            \
+        asm volatile(RTF_RECT_T_AND_POINT                                                                                \
                      "s_mov_b64 %[sv], exec\n\t"                                                                         \
                      "v_cmpx_le_f32 %[tmin], %[t]\n\t"                                                                   \
                      "v_cmpx_ge_f32 %[bt], %[t]\n\t"                                                                     \
@@ -165,7 +213,7 @@ RTF_DEV bool rect_in(const SRec &c, float ok, float ik, float oa, float da, floa
                      "s_mov_b64 exec, %[sv]"                                                                             \
                      : [t] "=&v"(t), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(saved), [bt] "+v"(best_t), [br] "+v"(best_rec) \
                      : [k] RC(k), [a0] RC(a0), [a1] RC(a1), [b0] RC(b0), [b1] RC(b1), [tmin] "s"(t_min), [idx] "s"(index), \
-                       [ok] "v"(ok), [ik] "v"(ik), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob), [db] "v"(db)                \
+                       [ok] "v"(ok), [dk] "v"(dk), [ik] "v"(ik), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob), [db] "v"(db)  \
                      : "vcc");                                                                                           \
     }
 RTF_RECT_UPDATE(rect_update_v, "v") // record fields in VGPRs (broadcast reads from LDS)
@@ -184,13 +232,13 @@ RTF_DEV LRec lds_rec(const uint32_t *lrecs, int i)
     r.k = lrecs[8 * i + 4];
     return r;
 }
-RTF_DEV void rect_run(const uint32_t *lrecs, int &index, int count, float t_min, float ok, float ik, float oa, float da, float ob,
-                      float db, float &best_t, int &best_rec)
+RTF_DEV void rect_run(const uint32_t *lrecs, int &index, int count, float t_min, float ok, float dk, float ik, float oa, float da,
+                      float ob, float db, float &best_t, int &best_rec)
 {
     for (int k = 0; k < count; ++k, ++index) {
         const LRec c = lds_rec(lrecs, index);
         rect_update_v(__uint_as_float(c.k), __uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
-                    t_min, index, ok, ik, oa, da, ob, db, best_t, best_rec);
+                    t_min, index, ok, dk, ik, oa, da, ob, db, best_t, best_rec);
     }
 }
 
@@ -198,11 +246,22 @@ RTF_DEV void rect_run(const uint32_t *lrecs, int &index, int count, float t_min,
 // the lane's best hit.  The nearest face hit inside (t_min, best] is the entry into the intersection of the three slabs,
 // or the exit when the entry lies before t_min (the origin is inside, or on the face it leaves): one slab test, 27
 // vector instructions, instead of six rect tests (72).  Which face it was is worked out after the scan (box_normal).
+RTF_DEV float slab_div(float n, float d, float y)
+{
+#ifdef RT_FAST_APPROX_T
+    return n * y;
+#else
+    return __builtin_amdgcn_div_fixupf(div_rn(n, d, y), d, n);
+#endif
+}
 RTF_DEV void slab_range(V3 lo, V3 hi, const LocalRay &l, float &tn, float &tf)
 {
-    const float x0 = (lo.x - l.o.x) * l.inv.x, x1 = (hi.x - l.o.x) * l.inv.x;
-    const float y0 = (lo.y - l.o.y) * l.inv.y, y1 = (hi.y - l.o.y) * l.inv.y;
-    const float z0 = (lo.z - l.o.z) * l.inv.z, z1 = (hi.z - l.o.z) * l.inv.z;
+    // each plane's distance is the t the reference's face rect computes, so the t of a box hit is its face's t.  A
+    // direction component of exactly 0 makes refined_rcp (and so div_rn) a NaN; v_div_fixup puts the IEEE special
+    // cases back (n/0 = +-inf: the slab on that axis is everything or nothing), which min/max need here.
+    const float x0 = slab_div(lo.x - l.o.x, l.d.x, l.inv.x), x1 = slab_div(hi.x - l.o.x, l.d.x, l.inv.x);
+    const float y0 = slab_div(lo.y - l.o.y, l.d.y, l.inv.y), y1 = slab_div(hi.y - l.o.y, l.d.y, l.inv.y);
+    const float z0 = slab_div(lo.z - l.o.z, l.d.z, l.inv.z), z1 = slab_div(hi.z - l.o.z, l.d.z, l.inv.z);
     tn = fmax3(fminf(x0, x1), fminf(y0, y1), fminf(z0, z1));
     tf = fmin3(fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1));
 }
@@ -233,6 +292,29 @@ RTF_DEV void box_run(const uint32_t *lrecs, int &index, int count, float t_min, 
     }
 }
 
+// sphere::hit's discriminant and roots (src/sphere.h:26-47) with the reference's operations one by one: dot products as
+// ((x*x + y*y) + z*z), IEEE square root, quotients correctly rounded (div_rn with 1/a refined once per ray).
+// dd = ref_dot(d, d), inv_dd = refined_rcp(dd).
+RTF_DEV float ref_dot(V3 a, V3 b) { return add_rn(add_rn(mul_rn(a.x, b.x), mul_rn(a.y, b.y)), mul_rn(a.z, b.z)); }
+RTF_DEV void sphere_roots(V3 o, V3 d, float dd, float inv_dd, float cx, float cy, float cz, float radius, float &disc, float &t1,
+                          float &t2)
+{
+    const V3 oc = v3(o.x - cx, o.y - cy, o.z - cz);
+#ifdef RT_FAST_APPROX_T
+    const float b = fdot(oc, d);
+    const float cc = fmaf(-radius, radius, fdot(oc, oc));
+    disc = fmaf(b, b, -(dd * cc));
+    const float sq = fsqrt(disc);
+    t1 = (-b - sq) * inv_dd, t2 = (sq - b) * inv_dd;
+#else
+    const float b = ref_dot(oc, d);
+    const float cc = sub_rn(ref_dot(oc, oc), mul_rn(radius, radius));
+    disc = sub_rn(mul_rn(b, b), mul_rn(dd, cc));
+    const float sq = sqrtf(disc); // correctly rounded (hipcc's default for sqrtf)
+    t1 = div_rn(sub_rn(-b, sq), dd, inv_dd), t2 = div_rn(add_rn(-b, sq), dd, inv_dd);
+#endif
+}
+
 // The scan of a flat stream stored in runs (rt_records.h): per chain three loops of rects (one per axis) and one of
 // boxes, then the spheres; run lengths come from the kernel arguments, so a record costs its fetch, its test and the loop's counter.
 // `lrecs`: the record stream in LDS; `recs`: the table in memory (instance chains, read with scalar loads).
@@ -247,24 +329,24 @@ RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs,
     for (int r = 0; r < Y.n_runs; ++r) {
         const uint32_t w = Y.run[r];
         if ((w >> 15) & RT_KW_CHAIN_MASK) apply_chain(recs, (w >> 15) & RT_KW_CHAIN_MASK, wr, l);
-        rect_run(lrecs, index, (int)((w >> 10) & 31u), t_min, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, best_t, best_rec);
-        rect_run(lrecs, index, (int)((w >> 5) & 31u), t_min, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, best_t, best_rec);
-        rect_run(lrecs, index, (int)(w & 31u), t_min, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best_t, best_rec);
+        rect_run(lrecs, index, (int)((w >> 10) & 31u), t_min, l.o.z, l.d.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, best_t, best_rec);
+        rect_run(lrecs, index, (int)((w >> 5) & 31u), t_min, l.o.y, l.d.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, best_t, best_rec);
+        rect_run(lrecs, index, (int)(w & 31u), t_min, l.o.x, l.d.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best_t, best_rec);
         box_run(lrecs, index, (int)(w >> 24), t_min, l, best_t, best_rec);
     }
     // spheres, world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree.  The smaller root is
     // the hit if it lies behind t_min, else only the larger one can be; best_t <= t_max, and a negative discriminant
     // makes every comparison false, so the update is three narrowing comparisons (as in rect_update_v).
+#ifdef RT_FAST_APPROX_T
     const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
+#else
+    const float w_dd = ref_dot(wr.d, wr.d), w_inv_dd = refined_rcp(w_dd);
+#endif
     for (int k = 0; k < Y.n_spheres; ++k, ++index) {
         const LRec c = lds_rec(lrecs, index);
-        const V3 oc = v3(wr.o.x - __uint_as_float(c.a.x), wr.o.y - __uint_as_float(c.a.y), wr.o.z - __uint_as_float(c.a.z));
-        const float radius = __uint_as_float(c.a.w);
-        const float b = fdot(oc, wr.d);
-        const float cc = fmaf(-radius, radius, fdot(oc, oc));
-        const float disc = fmaf(b, b, -(w_dd * cc));
-        const float sq = fsqrt(disc);
-        const float t1 = (-b - sq) * w_inv_dd, t2 = (sq - b) * w_inv_dd;
+        float disc, t1, t2;
+        sphere_roots(wr.o, wr.d, w_dd, w_inv_dd, __uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
+                     disc, t1, t2);
         float t;
         unsigned long long saved;
         asm volatile("v_cmp_lt_f32 vcc, %[tmin], %[t1]\n\t"
@@ -298,7 +380,11 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, cons
     LocalRay w, l; // world ray, ray of the current chain
     set_local(w, wr.o, wr.d);
     l = w;
+#ifdef RT_FAST_APPROX_T
     const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
+#else
+    const float w_dd = ref_dot(wr.d, wr.d), w_inv_dd = refined_rcp(w_dd);
+#endif
 
     // A plain counted loop keeps i in an SGPR.  A lane that missed a box carries `resume`, the index
     // after that subtree; when every lane is skipping, a record costs one compare and one branch.
@@ -336,22 +422,17 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, cons
         bool in;
         if (kind == RT_REC_RECT) { // src/plane.h:9-29, 47-67, 109-129
             const uint32_t axis = (kw >> RT_KW_AXIS_SHIFT) & 3u;
-            if (axis == 0) in = rect_in(c, l.o.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, t_min, best_t, t);
-            else if (axis == 1) in = rect_in(c, l.o.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, t_min, best_t, t);
-            else in = rect_in(c, l.o.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, t_min, best_t, t);
+            if (axis == 0) in = rect_in(c, l.o.z, l.d.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, t_min, best_t, t);
+            else if (axis == 1) in = rect_in(c, l.o.y, l.d.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, t_min, best_t, t);
+            else in = rect_in(c, l.o.x, l.d.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, t_min, best_t, t);
         } else if (kind == RT_REC_BOX) { // src/box.h as one slab test (box_update_v)
             float tn, tf;
             slab_range(v3(sf(c, 0), sf(c, 1), sf(c, 2)), v3(sf(c, 4), sf(c, 5), sf(c, 6)), l, tn, tf);
             t = tn >= t_min ? tn : tf;
             in = (tn <= tf) & (t >= t_min) & (t <= best_t);
         } else { // sphere, world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree
-            const V3 oc = v3(wr.o.x - sf(c, 0), wr.o.y - sf(c, 1), wr.o.z - sf(c, 2));
-            const float radius = sf(c, 3);
-            const float b = fdot(oc, wr.d);
-            const float cc = fmaf(-radius, radius, fdot(oc, oc));
-            const float disc = fmaf(b, b, -(w_dd * cc));
-            const float sq = fsqrt(disc);
-            const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
+            float disc, t1, t2;
+            sphere_roots(wr.o, wr.d, w_dd, w_inv_dd, sf(c, 0), sf(c, 1), sf(c, 2), sf(c, 3), disc, t1, t2);
             const bool in1 = (t1 < t_max) & (t1 > t_min), in2 = (t2 < t_max) & (t2 > t_min);
             t = in1 ? t1 : t2;
             in = (disc > 0.0f) & (in1 | in2) & (t <= best_t);
