@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
 {
     __shared__ float tile_acc[WAVES_PER_BLOCK][64 * 3];
     __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8]; // the record table, for the broadcast reads of the flat scan
-    for (int k = threadIdx.x; k < (RT_REC_MAX + 1) * 8; k += 64 * WAVES_PER_BLOCK) lrecs[k] = recs[k];
+    rtf::stage_records(recs, lrecs, Y.n_stream, threadIdx.x, 64 * WAVES_PER_BLOCK);
     __syncthreads(); // before any wave leaves
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -414,7 +414,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int task = blockIdx.x; // CHAIN: the first one; the counter hands out gridDim.x, gridDim.x + 1, ...
-    for (int k = tid; k < (RT_REC_MAX + 1) * 8; k += NT) lrecs[k] = recs[k];
+    rtf::stage_records(recs, lrecs, Y.n_stream, tid, NT);
     if (tid < (int)(sizeof(rt_camera) / 4)) reinterpret_cast<uint32_t *>(&lcam)[tid] = reinterpret_cast<const uint32_t *>(&S.cam)[tid];
     rtf::Regs R;
     load_records(recs, lane, R);
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
                                                          float t_max, rt_hit *__restrict__ out)
 {
     __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
-    for (int k = threadIdx.x; k < (RT_REC_MAX + 1) * 8; k += 256) lrecs[k] = recs[k];
+    rtf::stage_records(recs, lrecs, Y.n_stream, threadIdx.x, 256);
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;

@@ -171,74 +171,89 @@ RTF_DEV bool rect_in(const SRec &c, float ok, float dk, float ik, float oa, floa
     return (t >= t_min) & (t <= bound) & (a >= sf(c, 0)) & (a <= sf(c, 1)) & (b >= sf(c, 2)) & (b <= sf(c, 3));
 }
 
-// One rect record against the ray of its chain, and the update of the lane's best hit, as ONE block of machine code.
+// The lane's best hit so far is ONE 64-bit number (rt_records.h, RT_REC_KEY): t's bits above the record's key.  A hit
+// replaces it iff its number is smaller -- nearer, or exactly as near and met later by the reference's depth-first walk
+// (src/bvh.h:132-139: the right child wins a tie) -- so the order of the stream decides nothing.  t > 0 for every
+// candidate (t >= t_min is tested first), so the bits of t order like t.
+typedef unsigned long long Best;
+RTF_DEV Best best_start(float t_max) { return ((Best)__float_as_uint(t_max) << 32) | RT_REC_KEY_NONE; }
+RTF_DEV Best best_of(float t, uint32_t key) { return ((Best)__float_as_uint(t) << 32) | key; }
+RTF_DEV float best_t_of(Best b) { return __uint_as_float((uint32_t)(b >> 32)); }
+RTF_DEV int best_rec_of(Best b) { return (uint32_t)b == RT_REC_KEY_NONE ? -1 : (int)((uint32_t)b & 255u); }
+
+// One rect record against the ray of its chain, and the update of the lane's best hit.
 // What the compiler makes of rect_in() is 6 v_cmp + 5 s_and_b64 + 2 v_cndmask; the SIMD issues one scalar instruction
 // per turn just like one vector instruction, and with the loop's own scalar work the scan was bound by the scalar pipe
-// (35 scalar against 13 vector instructions per record).  Here the six comparisons narrow EXEC one after the other
-// (v_cmpx), the two moves run under what is left, and EXEC is restored: 12 vector and 2 scalar instructions.
+// (35 scalar against 13 vector instructions per record).  Here the comparisons narrow EXEC one after the other
+// (v_cmpx), one 64-bit move runs under what is left, and EXEC is restored: 8 vector instructions for t and the in-plane
+// point (intrinsics: nothing is contracted or reordered), 7 for the decision, 2 scalar.
 // Comparisons in positive form, so a NaN is never a hit.
+RTF_DEV void rect_update_v(float k, uint32_t key, float a0, float a1, float b0, float b1, float t_min, float ok, float dk, float ik,
+                           float oa, float da, float ob, float db, Best &best)
+{
+    const float t = div_rn(sub_rn(k, ok), dk, ik);
 #ifdef RT_FAST_APPROX_T
-#define RTF_RECT_T_AND_POINT                                                                                             \
-    "v_sub_f32 %[t], %[k], %[ok]\n\t"                                                                                    \
-    "v_mul_f32 %[t], %[t], %[ik]\n\t"                                                                                    \
-    "v_fma_f32 %[a], %[t], %[da], %[oa]\n\t"                                                                             \
-    "v_fma_f32 %[b], %[t], %[db], %[ob]\n\t"
-#else // t = (k - o) / d correctly rounded (div_rn), the point with product and sum rounded one after the other
-#define RTF_RECT_T_AND_POINT                                                                                             \
-    "v_sub_f32 %[t], %[k], %[ok]\n\t"                                                                                    \
-    "v_mul_f32 %[a], %[t], %[ik]\n\t"                                                                                    \
-    "v_fma_f32 %[b], -%[a], %[dk], %[t]\n\t"                                                                             \
-    "v_fma_f32 %[t], %[b], %[ik], %[a]\n\t"                                                                              \
-    "v_mul_f32 %[a], %[t], %[da]\n\t"                                                                                    \
-    "v_add_f32 %[a], %[a], %[oa]\n\t"                                                                                    \
-    "v_mul_f32 %[b], %[t], %[db]\n\t"                                                                                    \
-    "v_add_f32 %[b], %[b], %[ob]\n\t"
+    const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
+#else
+    const float a = add_rn(oa, mul_rn(t, da)), b = add_rn(ob, mul_rn(t, db));
 #endif
-#define RTF_RECT_UPDATE(NAME, RC)                                                                                        \
-    RTF_DEV void NAME(float k, float a0, float a1, float b0, float b1, float t_min, int index, float ok, float dk, float ik, \
-                      float oa, float da, float ob, float db, float &best_t, int &best_rec)                               \
-    {                                                                                                                    \
-        float t, a, b;                                                                                                   \
-        unsigned long long saved;                                                                                        \
-        asm volatile(RTF_RECT_T_AND_POINT                                                                                \
-                     "s_mov_b64 %[sv], exec\n\t"                                                                         \
-                     "v_cmpx_le_f32 %[tmin], %[t]\n\t"                                                                   \
-                     "v_cmpx_ge_f32 %[bt], %[t]\n\t"                                                                     \
-                     "v_cmpx_le_f32 %[a0], %[a]\n\t"                                                                     \
-                     "v_cmpx_ge_f32 %[a1], %[a]\n\t"                                                                     \
-                     "v_cmpx_le_f32 %[b0], %[b]\n\t"                                                                     \
-                     "v_cmpx_ge_f32 %[b1], %[b]\n\t"                                                                     \
-                     "v_mov_b32 %[bt], %[t]\n\t"                                                                         \
-                     "v_mov_b32 %[br], %[idx]\n\t"                                                                       \
-                     "s_mov_b64 exec, %[sv]"                                                                             \
-                     : [t] "=&v"(t), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(saved), [bt] "+v"(best_t), [br] "+v"(best_rec) \
-                     : [k] RC(k), [a0] RC(a0), [a1] RC(a1), [b0] RC(b0), [b1] RC(b1), [tmin] "s"(t_min), [idx] "s"(index), \
-                       [ok] "v"(ok), [dk] "v"(dk), [ik] "v"(ik), [oa] "v"(oa), [da] "v"(da), [ob] "v"(ob), [db] "v"(db)  \
-                     : "vcc");                                                                                           \
-    }
-RTF_RECT_UPDATE(rect_update_v, "v") // record fields in VGPRs (broadcast reads from LDS)
+    const Best cand = best_of(t, key);
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_le_f32 %[tmin], %[t]\n\t"
+                 "v_cmpx_le_f32 %[a0], %[a]\n\t"
+                 "v_cmpx_ge_f32 %[a1], %[a]\n\t"
+                 "v_cmpx_le_f32 %[b0], %[b]\n\t"
+                 "v_cmpx_ge_f32 %[b1], %[b]\n\t"
+                 "v_cmpx_gt_u64 %[best], %[cand]\n\t"
+                 "v_mov_b64 %[best], %[cand]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved), [best] "+v"(best)
+                 : [t] "v"(t), [a] "v"(a), [b] "v"(b), [cand] "v"(cand), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
+                   [tmin] "s"(t_min)
+                 : "vcc");
+}
 
 // `count` rect records of one chain and axis from record `index` on: nothing to decode, the loop is fetch + test.
 // The records come from the block's copy of the table in LDS with broadcast reads (every lane the same address): the
 // LDS pipe is idle otherwise, the scalar pipe was the busy one, and the next record's read is in flight during the test.
+// In that copy (stage_records) a stream record carries its key: a rect in dword 4 (the plane moves to dword 5), a sphere
+// in dword 4, a box in dword 3.
 struct LRec {
     uint4 a;   // a0 a1 b0 b1 (rect) | cx cy cz r (sphere)
-    uint32_t k; // rect: the plane
+    uint2 kk;  // key; rect: the plane
 };
 RTF_DEV LRec lds_rec(const uint32_t *lrecs, int i)
 {
     LRec r;
     r.a = *reinterpret_cast<const uint4 *>(lrecs + 8 * i);
-    r.k = lrecs[8 * i + 4];
+    r.kk = *reinterpret_cast<const uint2 *>(lrecs + 8 * i + 4);
     return r;
 }
+// the block's copy of the record table (all RT_REC_MAX + 1 records), with the keys of the stream records put in;
+// every thread of the block calls it, the caller's barrier follows
+RTF_DEV void stage_records(const uint32_t *__restrict__ recs, uint32_t *lrecs, int n_stream, int tid, int n_threads)
+{
+    for (int k = tid; k < (RT_REC_MAX + 1) * 8; k += n_threads) {
+        const int i = k >> 3, j = k & 7;
+        uint32_t v = recs[k];
+        if (i < n_stream) {
+            const uint32_t kw = recs[8 * i + 7], kind = kw & 15u;
+            const uint32_t key = RT_REC_KEY(kw, i);
+            if (kind == RT_REC_RECT) v = j == 4 ? key : j == 5 ? recs[8 * i + 4] : v;
+            if (kind == RT_REC_SPHERE) v = j == 4 ? key : v;
+            if (kind == RT_REC_BOX) v = j == 3 ? key : v;
+        }
+        lrecs[k] = v;
+    }
+}
 RTF_DEV void rect_run(const uint32_t *lrecs, int &index, int count, float t_min, float ok, float dk, float ik, float oa, float da,
-                      float ob, float db, float &best_t, int &best_rec)
+                      float ob, float db, Best &best)
 {
     for (int k = 0; k < count; ++k, ++index) {
         const LRec c = lds_rec(lrecs, index);
-        rect_update_v(__uint_as_float(c.k), __uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
-                    t_min, index, ok, dk, ik, oa, da, ob, db, best_t, best_rec);
+        rect_update_v(__uint_as_float(c.kk.y), c.kk.x, __uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z),
+                      __uint_as_float(c.a.w), t_min, ok, dk, ik, oa, da, ob, db, best);
     }
 }
 
@@ -265,30 +280,29 @@ RTF_DEV void slab_range(V3 lo, V3 hi, const LocalRay &l, float &tn, float &tf)
     tn = fmax3(fminf(x0, x1), fminf(y0, y1), fminf(z0, z1));
     tf = fmin3(fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1));
 }
-RTF_DEV void box_update_v(V3 lo, V3 hi, float t_min, int index, const LocalRay &l, float &best_t, int &best_rec)
+RTF_DEV void box_update_v(V3 lo, V3 hi, uint32_t key, float t_min, const LocalRay &l, Best &best)
 {
-    float tn, tf, t;
+    float tn, tf;
     slab_range(lo, hi, l, tn, tf);
+    const float t = t_min <= tn ? tn : tf;
+    const Best cand = best_of(t, key);
     unsigned long long saved;
-    asm volatile("v_cmp_le_f32 vcc, %[tmin], %[tn]\n\t"
-                 "v_cndmask_b32 %[t], %[tf], %[tn], vcc\n\t"
-                 "s_mov_b64 %[sv], exec\n\t"
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
                  "v_cmpx_le_f32 %[tn], %[tf]\n\t"
                  "v_cmpx_le_f32 %[tmin], %[t]\n\t"
-                 "v_cmpx_ge_f32 %[bt], %[t]\n\t"
-                 "v_mov_b32 %[bt], %[t]\n\t"
-                 "v_mov_b32 %[br], %[idx]\n\t"
+                 "v_cmpx_gt_u64 %[best], %[cand]\n\t"
+                 "v_mov_b64 %[best], %[cand]\n\t"
                  "s_mov_b64 exec, %[sv]"
-                 : [t] "=&v"(t), [sv] "=&s"(saved), [bt] "+v"(best_t), [br] "+v"(best_rec)
-                 : [tn] "v"(tn), [tf] "v"(tf), [tmin] "s"(t_min), [idx] "s"(index)
+                 : [sv] "=&s"(saved), [best] "+v"(best)
+                 : [tn] "v"(tn), [tf] "v"(tf), [t] "v"(t), [cand] "v"(cand), [tmin] "s"(t_min)
                  : "vcc");
 }
-RTF_DEV void box_run(const uint32_t *lrecs, int &index, int count, float t_min, const LocalRay &l, float &best_t, int &best_rec)
+RTF_DEV void box_run(const uint32_t *lrecs, int &index, int count, float t_min, const LocalRay &l, Best &best)
 {
     for (int k = 0; k < count; ++k, index += 2) { // the record after a box is its second half
         const uint4 a = *reinterpret_cast<const uint4 *>(lrecs + 8 * index), b = *reinterpret_cast<const uint4 *>(lrecs + 8 * index + 4);
         box_update_v(v3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
-                     v3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)), t_min, index, l, best_t, best_rec);
+                     v3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)), a.w, t_min, l, best);
     }
 }
 
@@ -321,22 +335,20 @@ RTF_DEV void sphere_roots(V3 o, V3 d, float dd, float inv_dd, float cx, float cy
 RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min,
                        float t_max, bool alive, float &best_t, int &best_rec)
 {
-    best_t = t_max;
-    best_rec = -1;
+    Best best = best_start(t_max);
     LocalRay l;
     set_local(l, wr.o, wr.d);
     int index = 0;
     for (int r = 0; r < Y.n_runs; ++r) {
         const uint32_t w = Y.run[r];
         if ((w >> 15) & RT_KW_CHAIN_MASK) apply_chain(recs, (w >> 15) & RT_KW_CHAIN_MASK, wr, l);
-        rect_run(lrecs, index, (int)((w >> 10) & 31u), t_min, l.o.z, l.d.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, best_t, best_rec);
-        rect_run(lrecs, index, (int)((w >> 5) & 31u), t_min, l.o.y, l.d.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, best_t, best_rec);
-        rect_run(lrecs, index, (int)(w & 31u), t_min, l.o.x, l.d.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best_t, best_rec);
-        box_run(lrecs, index, (int)(w >> 24), t_min, l, best_t, best_rec);
+        rect_run(lrecs, index, (int)((w >> 10) & 31u), t_min, l.o.z, l.d.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, best);
+        rect_run(lrecs, index, (int)((w >> 5) & 31u), t_min, l.o.y, l.d.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, best);
+        rect_run(lrecs, index, (int)(w & 31u), t_min, l.o.x, l.d.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best);
+        box_run(lrecs, index, (int)(w >> 24), t_min, l, best);
     }
-    // spheres, world space: src/sphere.h:21-59 (strict range test), then the tie rule of the tree.  The smaller root is
-    // the hit if it lies behind t_min, else only the larger one can be; best_t <= t_max, and a negative discriminant
-    // makes every comparison false, so the update is three narrowing comparisons (as in rect_update_v).
+    // spheres, world space: src/sphere.h:21-59 (strict range test: t_min < t < t_max).  The smaller root is the hit if it
+    // lies behind t_min, else only the larger one can be; a negative discriminant makes every comparison false.
 #ifdef RT_FAST_APPROX_T
     const float w_dd = fdot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
 #else
@@ -347,22 +359,22 @@ RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs,
         float disc, t1, t2;
         sphere_roots(wr.o, wr.d, w_dd, w_inv_dd, __uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z), __uint_as_float(c.a.w),
                      disc, t1, t2);
-        float t;
+        const float t = t_min < t1 ? t1 : t2;
+        const Best cand = best_of(t, c.kk.x);
         unsigned long long saved;
-        asm volatile("v_cmp_lt_f32 vcc, %[tmin], %[t1]\n\t"
-                     "v_cndmask_b32 %[t], %[t2], %[t1], vcc\n\t"
-                     "s_mov_b64 %[sv], exec\n\t"
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
                      "v_cmpx_lt_f32 0, %[disc]\n\t"
                      "v_cmpx_lt_f32 %[tmin], %[t]\n\t"
-                     "v_cmpx_ge_f32 %[bt], %[t]\n\t"
-                     "v_mov_b32 %[bt], %[t]\n\t"
-                     "v_mov_b32 %[br], %[idx]\n\t"
+                     "v_cmpx_gt_f32 %[tmax], %[t]\n\t"
+                     "v_cmpx_gt_u64 %[best], %[cand]\n\t"
+                     "v_mov_b64 %[best], %[cand]\n\t"
                      "s_mov_b64 exec, %[sv]"
-                     : [t] "=&v"(t), [sv] "=&s"(saved), [bt] "+v"(best_t), [br] "+v"(best_rec)
-                     : [t1] "v"(t1), [t2] "v"(t2), [disc] "v"(disc), [tmin] "s"(t_min), [idx] "s"(index)
+                     : [sv] "=&s"(saved), [best] "+v"(best)
+                     : [t] "v"(t), [cand] "v"(cand), [disc] "v"(disc), [tmin] "s"(t_min), [tmax] "s"(t_max)
                      : "vcc");
     }
-    best_rec = alive ? best_rec : -1;
+    best_t = best_t_of(best);
+    best_rec = alive ? best_rec_of(best) : -1;
 }
 
 template <bool FLAT>
@@ -373,8 +385,8 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, cons
         scan_runs(recs, lrecs, Y, wr, t_min, t_max, alive, best_t, best_rec);
         return;
     }
-    best_t = t_max;
-    best_rec = -1;
+    Best best = best_start(t_max);
+    best_t = t_max; // the bound the tests below compare with: always the t of `best`
     int resume = 0;
     uint32_t cur_chain = 0;
     LocalRay w, l; // world ray, ray of the current chain
@@ -437,10 +449,13 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, cons
             t = in1 ? t1 : t2;
             in = (disc > 0.0f) & (in1 | in2) & (t <= best_t);
         }
-        const bool take = in & on;
+        // `in` holds t <= best_t; of two hits at the same t the one the reference's walk meets later wins (Best)
+        const Best cand = best_of(t, RT_REC_KEY(kw, i));
+        const bool take = in & on & (cand < best);
+        best = take ? cand : best;
         best_t = take ? t : best_t;
-        best_rec = take ? i : best_rec;
     }
+    best_rec = best_rec_of(best);
 }
 
 // what shading needs about the hit, built after the scan from the winning record

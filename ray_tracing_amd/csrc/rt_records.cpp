@@ -252,12 +252,21 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             emit_prim(s, en.a, p, p.chain, RT_KW_FIRST | RT_KW_LAST);
         }
     }
+    // Ranks: stream records are in the order of the reference's depth-first walk here (entries are stored in pre-order).
+    // A primitive the walk meets twice (the only object of a one-object node) takes the rank of its last visit.
+    {
+        std::map<int, int> last; // prim -> stream index of its last visit
+        for (int i = 0; i < n_stream; ++i)
+            if (out->prim[i] >= 0) last[out->prim[i]] = i;
+        for (int i = 0; i < n_stream; ++i)
+            if (out->prim[i] >= 0) out->rec[i][7] |= ((uint32_t)last[out->prim[i]] & RT_KW_RANK_MASK) << RT_KW_RANK_SHIFT;
+    }
     // A flat stream is stored in runs: chain by chain (world space first), within a chain the rects by axis and then
     // the boxes (each with its second record: the stable sort keeps the pair together), and all spheres (world space) at
     // the end.  The scan (rt_fast.hpp) then runs one tight loop per run, with nothing to decode
     // per record; the run lengths travel in the kernel arguments.  (More than RT_REC_MAX_RUNS chains: n_runs = 0 and the
     // generic scan, which decodes every record, is used.)
-    // The order of a flat stream only decides which of two hits at the SAME distance is kept.
+    // (The order of a flat stream decides nothing: of two hits at the same distance the rank decides, rt_records.h.)
     if (out->flat) {
         std::vector<int> order(n_stream);
         for (int i = 0; i < n_stream; ++i) order[i] = i;

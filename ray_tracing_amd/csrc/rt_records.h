@@ -22,6 +22,8 @@
 // kind word:  bits 0-3 kind | 4-5 rect axis (0 xy, 1 xz, 2 yz; 3 for BOX and BOX_AUX) | 6 flip | 7 first of its list | 8 last of its list
 //             | 9-14 first record of the instance chain | 15-17 number of chain records
 //             | 18-25 material record (relative to materials_base)
+//             | 26-31 stream records: RANK = where the reference's depth-first walk meets the primitive (its last visit);
+//               of two hits at exactly the same t the one met later wins (src/bvh.h:132-139), whatever the stream's order
 #ifndef RT_RECORDS_H_
 #define RT_RECORDS_H_
 
@@ -54,6 +56,13 @@ enum rt_rec_kind {
 #define RT_KW_CHAIN_MASK 0x1ffu
 #define RT_KW_MAT_SHIFT 18
 #define RT_KW_MAT_MASK 0xffu
+#define RT_KW_RANK_SHIFT 26   /* 6 bits */
+#define RT_KW_RANK_MASK 0x3fu
+/* The scan's per-lane best hit is ONE 64-bit number, smaller = better: t's bits (t > 0, so they order like t) above a key
+ * of the record, (63 - rank) << 8 | stream index.  A hit replaces the best iff its number is smaller: nearer, or as near
+ * and met later by the reference's walk. */
+#define RT_REC_KEY(kw, index) ((((RT_KW_RANK_MASK - (((kw) >> RT_KW_RANK_SHIFT) & RT_KW_RANK_MASK))) << 8) | (uint32_t)(index))
+#define RT_REC_KEY_NONE 0xffffffffu
 
 typedef struct rt_record_table {
     uint32_t rec[RT_REC_MAX + 1][8]; /* one spare record: the scan prefetches record i+1 */

@@ -28,3 +28,28 @@ def test_bench_line_has_the_contract_fields():
         assert key in r, key
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
     assert "cpu_baseline" not in out  # --no-cpu
+    assert out["n_ranks_seen"] == 1 and "no reduce at N=1" in out["config"]["partition"]
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without torch.distributed.run around it: the parent must start the two ranks itself
+    (a child process, before it touches torch or HIP), relay rank 0's single JSON line and return the child's exit code.
+    No GPU here: RT_BENCH_TEST_HOOK swaps the renderer for the CPU oracle and the backend for gloo, everything else --
+    launch, sample ranges, reduce, report -- is the code the driver runs."""
+    env = dict(os.environ, RT_BENCH_TEST_HOOK="bench_hook:oracle_renderer")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "24",
+                        "--spp", "6"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["steps"] == 1
+    assert "one RCCL sum-reduce" in out["config"]["partition"] and "2 GPUs" in out["config"]["partition"]
+    assert out["value"] > 0 and "cpu_baseline" not in out
+    # a failing child's exit code comes back
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "24",
+                          "--spp", "6"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path),
+                         env=dict(env, RT_BENCH_TEST_HOOK="bench_hook:no_such_function"))
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

@@ -115,6 +115,35 @@ def test_fast_path_agrees_with_exact_path_on_incoherent_rays(cornell_host):
     assert np.allclose(fast["normal"][m], exact["normal"][m], atol=1e-3)
 
 
+def test_fast_path_resolves_exact_ties_like_the_reference(cornell_host):
+    """Rays in the planes x = y and x + y = 555 through the room's centre line meet two walls at EXACTLY the same t along
+    the room's edges (the same subtraction and division on both axes).  bvh_node::hit gives such a tie to the primitive
+    its depth-first walk meets later (src/bvh.h:132-139); the fast path's scan visits records in another order
+    (by chain and axis) and settles ties by rank (rt_records.h), so the ids must still agree with the oracle's."""
+    rng = np.random.default_rng(23)
+    n = 40000
+    c = np.float32(277.5)
+    oz = rng.uniform(-800, 500, size=n).astype(np.float32)
+    o = np.stack([np.full(n, c), np.full(n, c), oz], axis=1)
+    a = rng.uniform(0.05, 1.0, size=n).astype(np.float32)
+    sx = np.where(rng.integers(0, 2, size=n) == 0, -1.0, 1.0).astype(np.float32)
+    sy = np.where(rng.integers(0, 2, size=n) == 0, -1.0, 1.0).astype(np.float32)
+    d = np.stack([sx * a, sy * a, rng.uniform(-1, 1, size=n).astype(np.float32)], axis=1)
+    rays = np.concatenate([o, d, np.zeros((n, 1), np.float32)], axis=1).astype(np.float32)
+    sc = Scene(cornell_host, 0)
+    sc.set_path(trace=_capi.RT_PATH_FAST)
+    fast = api.trace_rays(sc, rays)
+    sc.close()
+    cpu = O.trace_rays(cornell_host, rays)
+    assert np.array_equal(fast["prim_id"], cpu["prim_id"]), f"{(fast['prim_id'] != cpu['prim_id']).sum()} ids differ"
+    m = cpu["prim_id"] >= 0
+    assert np.array_equal(bits(fast["t"][m]), bits(cpu["t"][m]))
+    # the construction does produce edge hits: both walls' planes are reached at the same t on a good part of the rays
+    t_x = (np.where(sx < 0, np.float32(0.0), np.float32(555.0)) - c) / d[:, 0]
+    on_edge = m & (cpu["t"] == t_x.astype(np.float32))
+    assert on_edge.sum() > 1000
+
+
 def test_trace_edge_cases(cornell_gpu, cornell_host):
     assert len(api.trace_rays(cornell_gpu, np.zeros((0, 7), np.float32))) == 0
     one = np.array([[278, 278, -800, 0, 0, 1, 0]], dtype=np.float32)
