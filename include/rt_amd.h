@@ -167,7 +167,18 @@ typedef struct rt_scene rt_scene; /* opaque, device-resident */
  * hand-off to the render tasks (src/main.cpp:505-511, 545-554).  `device` is
  * the HIP device ordinal.  Validates every index in the description. */
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+/* The same with flags (rt_scene_create passes 0).  RT_CREATE_KEEP_BOX_RECORDS: a small scene keeps the inner nodes of
+ * the reference's tree in its record table (normally dropped at <= 16 primitives): a test aid that sends such a
+ * scene through the generic scan.  No counterpart in the reference. */
+#define RT_CREATE_KEEP_BOX_RECORDS 1u
+int rt_scene_create_flags(const rt_scene_desc* desc, int device, uint32_t flags, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
+
+/* Threading and devices.  A scene belongs to the device it was created on; every entry point that takes a scene makes
+ * that device current for the calling thread and leaves it current.  One host thread at a time per rt_scene: the
+ * calls are not re-entrant on one scene (launch bookkeeping, the timing events).  rt_last_render_ms refers to the
+ * latest rt_render of the scene.  rt_resolve takes no scene: it runs on the calling thread's CURRENT device, which
+ * must be the one that holds d_accum and d_rgba8.  Different scenes may be used from different threads. */
 
 /* ------------------------------------------------------------------ */
 /* Render                                                               */
@@ -263,10 +274,27 @@ int rt_trace_rays_noalloc(rt_scene* scene, int32_t n, const float* h_rays, float
  * RT_PATH_AUTO (default): rt_render uses FAST whenever one of its two forms can run the scene (EXACT is left
  * for what neither can: RT_INFO_FAST_PATH_AVAILABLE == 0); rt_trace_rays uses EXACT.
  * No counterpart in the reference (it has one CPU path). */
-enum rt_option { RT_OPT_RENDER_PATH = 1, RT_OPT_TRACE_PATH = 2 };
+enum rt_option {
+    RT_OPT_RENDER_PATH = 1, /* rt_path */
+    RT_OPT_TRACE_PATH = 2,  /* rt_path */
+    /* Tuning and test switches of rt_render; none changes what is computed (paths are keyed by pixel and sample),
+     * only how the work is cut up.  0 = the library's own choice unless said otherwise.  (They are options of a scene
+     * on purpose, not environment variables: nothing outside the caller's code can change which kernel runs.) */
+    RT_OPT_BLOCK_KERNEL = 3,        /* 1 (default): record-table scenes without textures run the block kernel; 0: the wave kernel */
+    RT_OPT_CHAIN_TASKS = 4,         /* 1 (default): waves / blocks take task after task from a counter; 0: one task each */
+    RT_OPT_TARGET_TASKS = 5,        /* tasks a launch is cut into (default 262144 waves' worth) */
+    RT_OPT_PATHS_PER_LANE = 6,      /* lower bound on a task's size, in paths per lane */
+    RT_OPT_NODE_STEPS = 7,          /* per-lane walk: node steps between two looks at who waits (2 or 4) */
+    RT_OPT_CHAIN_BLOCKS_PER_CU = 8  /* per-lane walk: blocks per CU of the chained grid */
+};
 enum rt_path { RT_PATH_AUTO = 0, RT_PATH_EXACT = 1, RT_PATH_FAST = 2 };
 int rt_scene_set_option(rt_scene* scene, int option, int value);
-enum rt_info { RT_INFO_FAST_PATH_AVAILABLE = 1, RT_INFO_LAST_RENDER_PATH = 2, RT_INFO_RECORDS = 3 };
+enum rt_info {
+    RT_INFO_FAST_PATH_AVAILABLE = 1,
+    RT_INFO_LAST_RENDER_PATH = 2,
+    RT_INFO_RECORDS = 3,
+    RT_INFO_BVH_LEVELS = 4 /* inner levels of the library's own tree (per-lane fast path), 0 when the scene has none */
+};
 int rt_scene_get_info(rt_scene* scene, int what, int* value);
 
 /* ------------------------------------------------------------------ */

@@ -8,6 +8,9 @@ The fixtures are inputs and expected outputs (data), not source.
 
     python oracle/make_golden.py            # everything except the slow converged image
     python oracle/make_golden.py --scenes cornell_box --image   # + Cornell 256x256 at 1024/4096/8192 spp (about 25 minutes)
+    python oracle/make_golden.py --scenes cornell_box --image96 --only-images   # Cornell 96x96 at 4096/8192 spp (3 minutes):
+        # the converged image that stays INSIDE the period of the reference's minstd_rand0 (2^31-2 draws; a path takes
+        # about 25, so 96*96*8192 paths draw 1.9e9), which a 256x256 render leaves after about 1300 spp
 """
 import argparse
 import os
@@ -31,6 +34,8 @@ def run(*args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--image", action="store_true", help="also render the 4096-spp converged image")
+    ap.add_argument("--image96", action="store_true", help="also render the within-period 96x96 converged images")
+    ap.add_argument("--only-images", action="store_true", help="leave the .npz fixtures and kat.npz as they are")
     ap.add_argument("--scenes", default="cornell_box,cornell_box_volumes,random_spheres,next_week_final")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -55,15 +60,23 @@ def main():
                 out["samples_32x24_s2_S1_r50"] = np.load(f"{tmp}/s.npy")
                 run("hits", scene, 64, 48, f"{tmp}/h.npy")
                 out["hits_64x48"] = np.load(f"{tmp}/h.npy")
-            np.savez_compressed(os.path.join(GOLD, f"{scene}.npz"), **out)
+            if a.only_images:
+                out = None
+            if out is not None:
+                np.savez_compressed(os.path.join(GOLD, f"{scene}.npz"), **out)
+            if a.image96:
+                for spp in (4096, 8192):
+                    run("image", scene, 96, 96, spp, 50, f"{tmp}/i.npy")
+                    np.save(os.path.join(GOLD, f"{scene}_96x96_{spp}spp_r50.npy"), np.load(f"{tmp}/i.npy"))
             if a.image:
                 for spp in (1024, 4096, 8192):  # 8192 also shows where the reference's minstd stream starts to replay
                     run("image", scene, 256, 256, spp, 50, f"{tmp}/i.npy")
                     np.save(os.path.join(GOLD, f"{scene}_256x256_{spp}spp_r50.npy"), np.load(f"{tmp}/i.npy"))
-        os.makedirs(f"{tmp}/kat")
-        run("kat", f"{tmp}/kat")
-        kat = {f[:-4]: np.load(f"{tmp}/kat/{f}") for f in sorted(os.listdir(f"{tmp}/kat"))}
-        np.savez_compressed(os.path.join(GOLD, "kat.npz"), **kat)
+        if not a.only_images:
+            os.makedirs(f"{tmp}/kat")
+            run("kat", f"{tmp}/kat")
+            kat = {f[:-4]: np.load(f"{tmp}/kat/{f}") for f in sorted(os.listdir(f"{tmp}/kat"))}
+            np.savez_compressed(os.path.join(GOLD, "kat.npz"), **kat)
     print("wrote", sorted(os.listdir(GOLD)))
 
 

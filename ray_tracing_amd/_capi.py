@@ -17,8 +17,11 @@ RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM = -1, -2, -3,
 RT_RENDER_ACCUMULATE = 1
 RT_TRACE_NOALLOC_MAX_RAYS = 65536
 RT_OPT_RENDER_PATH, RT_OPT_TRACE_PATH = 1, 2
+(RT_OPT_BLOCK_KERNEL, RT_OPT_CHAIN_TASKS, RT_OPT_TARGET_TASKS, RT_OPT_PATHS_PER_LANE, RT_OPT_NODE_STEPS,
+ RT_OPT_CHAIN_BLOCKS_PER_CU) = range(3, 9)
+RT_CREATE_KEEP_BOX_RECORDS = 1
 RT_PATH_AUTO, RT_PATH_EXACT, RT_PATH_FAST = 0, 1, 2
-RT_INFO_FAST_PATH_AVAILABLE, RT_INFO_LAST_RENDER_PATH, RT_INFO_RECORDS = 1, 2, 3
+RT_INFO_FAST_PATH_AVAILABLE, RT_INFO_LAST_RENDER_PATH, RT_INFO_RECORDS, RT_INFO_BVH_LEVELS = 1, 2, 3, 4
 
 # enum values (include/rt_amd.h)
 RT_ENTRY_INNER, RT_ENTRY_LEAF = 0, 1
@@ -94,6 +97,7 @@ assert C.sizeof(rt_hit) == 48 and C.sizeof(rt_material) == 16
 PROTOTYPES = {
     # include/rt_amd.h
     "rt_scene_create": (C.c_int, [C.POINTER(rt_scene_desc), C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_scene_create_flags": (C.c_int, [C.POINTER(rt_scene_desc), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(rt_render_params), C.c_void_p, C.c_void_p]),
     "rt_resolve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -47,12 +47,16 @@ class HostScene:
 class Scene:
     """Device-resident scene (rt_scene_create)."""
 
-    def __init__(self, host_scene, device=0):
+    def __init__(self, host_scene, device=0, create_flags=0):
         lib = _capi.load()
         self.host = host_scene if isinstance(host_scene, HostScene) else HostScene(host_scene)
         self.device = device
         self._s = C.c_void_p()
-        _check(lib.rt_scene_create(self.host.desc, device, C.byref(self._s)), "rt_scene_create")
+        _check(lib.rt_scene_create_flags(self.host.desc, device, create_flags, C.byref(self._s)), "rt_scene_create_flags")
+
+    def set_option(self, option, value):
+        """rt_scene_set_option for the tuning / test switches (RT_OPT_BLOCK_KERNEL, RT_OPT_CHAIN_TASKS, ...)."""
+        _check(_capi.load().rt_scene_set_option(self._s, option, value), "rt_scene_set_option")
 
     def set_path(self, render=None, trace=None):
         """rt_scene_set_option: choose RT_PATH_AUTO / RT_PATH_EXACT / RT_PATH_FAST for rt_render / rt_trace_rays."""

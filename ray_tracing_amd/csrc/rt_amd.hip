@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -907,11 +908,13 @@ struct rt_scene {
     int32_t *d_rec_user = nullptr;
     unsigned *d_task_counters = nullptr; // inside blob: 64 task counters of the chained kernels, used in turn (each zeroed
                                          // before its launch), so launches on different streams do not share one
-    unsigned launch_seq = 0;
+    std::atomic<unsigned> launch_seq{0};
     unsigned char *scratch = nullptr; // this device's copy of the static staging area (rt_trace_rays_noalloc)
     int n_cus = 256;
     int render_path = RT_PATH_AUTO, trace_path = RT_PATH_AUTO;
     int last_render_path = RT_PATH_EXACT;
+    // rt_scene_set_option: tuning / test switches of rt_render (0 = the library's choice)
+    int opt_block_kernel = 1, opt_chain = 1, opt_target_tasks = 0, opt_paths_per_lane = 0, opt_node_steps = 0, opt_chain_blocks_per_cu = 0;
 };
 
 #define RT_HIP(call)                                                                                                   \
@@ -998,6 +1001,10 @@ static int validate(const rt_scene_desc *d)
                 const rt_prim &c = d->prims[p.first + k];
                 if (!plain(c.kind) || c.material < 0 || c.material >= d->n_materials)
                     return rt_fail(RT_ERR_INVALID, "rt_scene_create: group %d child %d must be a plain primitive with a material", i, k);
+                // a list is one object under one instance chain (src/hitable_list.h, src/transforms.h); the render paths
+                // apply the GROUP's chain to its members
+                if (c.chain != p.chain)
+                    return rt_fail(RT_ERR_INVALID, "rt_scene_create: group %d child %d carries chain %d, its group chain %d", i, k, c.chain, p.chain);
             }
         } else {
             if (p.material < 0 || p.material >= d->n_materials)
@@ -1025,8 +1032,13 @@ static int validate(const rt_scene_desc *d)
     for (int i = 0; i < d->n_lights; ++i) {
         int l = d->lights[i];
         if (l >= d->n_prims) return rt_fail(RT_ERR_INVALID, "rt_scene_create: light %d out of range", i);
+        if (l < -1) return rt_fail(RT_ERR_INVALID, "rt_scene_create: light %d is %d (a primitive index, or -1)", i, l);
         if (l >= 0 && d->prims[l].kind != RT_PRIM_XZ_RECT && d->prims[l].kind != RT_PRIM_SPHERE)
             return rt_fail(RT_ERR_INVALID, "rt_scene_create: light %d must be an xz_rect or a sphere (or -1)", i);
+        // translate / rotate_y do not forward pdf_value / random (src/hitable.h:19-20), so a member under an instance chain
+        // samples as "no override": it must be given as -1 (rt_flatten does), its coordinates are never used as world space
+        if (l >= 0 && d->prims[l].chain != 0)
+            return rt_fail(RT_ERR_INVALID, "rt_scene_create: light %d is under an instance chain; pass -1 for it (src/hitable.h:19-20)", i);
     }
     bool lambert = false;
     for (int i = 0; i < d->n_materials; ++i) lambert |= d->materials[i].kind == RT_MAT_LAMBERTIAN;
@@ -1043,9 +1055,12 @@ extern "C" int rt_device_count(void)
     return n;
 }
 
-extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out)
+extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) { return rt_scene_create_flags(d, device, 0u, out); }
+
+extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_t flags, rt_scene **out)
 {
     if (!out) return rt_fail(RT_ERR_INVALID, "rt_scene_create: null output");
+    if (flags & ~RT_CREATE_KEEP_BOX_RECORDS) return rt_fail(RT_ERR_INVALID, "rt_scene_create_flags: unknown flags 0x%x", flags);
     *out = nullptr;
     int st = validate(d);
     if (st != RT_OK) return st;
@@ -1064,7 +1079,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, rt_scene **ou
     };
     rt_record_table tab;
     const char *why = "";
-    const bool fast_ok = rt_records_build(d, &tab, &why) != 0;
+    const bool fast_ok = rt_records_build(d, (flags & RT_CREATE_KEEP_BOX_RECORDS) ? 1 : 0, &tab, &why) != 0;
     std::vector<int32_t> order;
     int tree_depth = 0;
     const bool ordered = rt_order_build(d, order, &tree_depth);
@@ -1205,7 +1220,7 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     // the record-table path has two kernels: one wave per 8x8 tile (render_fast_kernel), or one block of four waves per
     // 16x16 tile that regroups its paths by class between scan and shade (render_fast_block_kernel: no textures, depth
     // and light list small enough for its packed state word)
-    const bool block_off = getenv("RT_AMD_NO_BLOCK_KERNEL") != nullptr; // tuning / test aid: the wave kernel instead
+    const bool block_off = s->opt_block_kernel == 0; // RT_OPT_BLOCK_KERNEL: the wave kernel instead
     const bool block_kernel = use_fast && s->fast_ok && !s->fast_textured && !block_off && p->max_depth < 65536 && s->layout.n_lights <= 16;
     const int tile_w = block_kernel ? 4 * BLOCK_WAVES : 8, tile_h = block_kernel ? 16 : 8, waves_per_task = block_kernel ? BLOCK_WAVES : 1;
     RenderArgs A{};
@@ -1221,15 +1236,15 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     // random spheres 64 spp 6.5 / 6.1 / 6.7 / 6.5, Next-Week final 1.61 / 1.74 / 1.79 / 1.67, 1M spheres 16 spp
     // 1.06 / 1.16 / 1.19 / 1.06 Gpaths/s.
     int64_t target_tasks = 262144;
-    if (const char *e = getenv("RT_AMD_TARGET_TASKS")) target_tasks = atoll(e) > 0 ? atoll(e) : target_tasks; // tuning aid
+    if (s->opt_target_tasks > 0) target_tasks = s->opt_target_tasks; // RT_OPT_TARGET_TASKS
     target_tasks /= waves_per_task;
     int64_t want_chunks = (target_tasks + tiles - 1) / tiles;
     const int64_t all_paths = (int64_t)ns * p->sub_samples;
-    // chained kernels (tools: RT_AMD_NO_CHAIN=1 for the one-task-per-wave / per-block forms)
-    const bool chain = block_kernel && getenv("RT_AMD_NO_CHAIN") == nullptr;
-    A.chain = (use_fast && s->lanes_ok && getenv("RT_AMD_NO_CHAIN") == nullptr) ? 1 : 0;
+    // chained kernels (RT_OPT_CHAIN_TASKS = 0: the one-task-per-wave / per-block forms)
+    const bool chain = block_kernel && s->opt_chain != 0;
+    A.chain = (use_fast && s->lanes_ok && s->opt_chain != 0) ? 1 : 0;
     int64_t hi_paths = (chain || A.chain) ? 8 : 16, lo_paths = hi_paths / 2;
-    if (const char *e = getenv("RT_AMD_PATHS_PER_LANE")) { hi_paths = atoll(e) > 0 ? atoll(e) : hi_paths; lo_paths = std::max<int64_t>(1, hi_paths / 2); } // tuning aid
+    if (s->opt_paths_per_lane > 0) { hi_paths = s->opt_paths_per_lane; lo_paths = std::max<int64_t>(1, hi_paths / 2); } // RT_OPT_PATHS_PER_LANE
     const int64_t want = want_chunks, cap_hi = (all_paths + hi_paths - 1) / hi_paths, cap_lo = (all_paths + lo_paths - 1) / lo_paths;
     if (want_chunks > cap_hi) want_chunks = cap_hi;
     const int64_t few = 49152 / waves_per_task; // below this many tasks the end of the launch shows: the lower bound on paths per lane
@@ -1250,18 +1265,18 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     A.n_tasks = (int)n_tasks;
     if (A.atomic_out && !accumulate) RT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
     const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    unsigned *const d_task_counter = s->d_task_counters + (s->launch_seq++ & 63u);
+    unsigned *const d_task_counter = s->d_task_counters + (s->launch_seq.fetch_add(1u) & 63u);
     RT_HIP(hipEventRecord(s->ev0, stream));
     if (use_fast && s->lanes_ok) {
         // chained: as many blocks as the chip holds at once (six waves per SIMD), each wave takes tasks from the counter
         int64_t per_cu = RT_LANES_WAVES_PER_EU;
-        if (const char *e = getenv("RT_AMD_CHAIN_BLOCKS_PER_CU")) per_cu = atoll(e) > 0 ? atoll(e) : per_cu; // tuning aid
+        if (s->opt_chain_blocks_per_cu > 0) per_cu = s->opt_chain_blocks_per_cu; // RT_OPT_CHAIN_BLOCKS_PER_CU
         const dim3 g((unsigned)(A.chain ? std::min<int64_t>(blocks, (int64_t)s->n_cus * per_cu) : blocks)), b(64 * WAVES_PER_BLOCK);
         if (A.chain) RT_HIP(hipMemsetAsync(d_task_counter, 0, sizeof(unsigned), stream));
         const size_t lds = (size_t)WAVES_PER_BLOCK * s->bvh_levels * 256; // the walks' stacks
         A.stack_levels = s->bvh_levels;
         int steps = s->bvh_levels > 20 ? 4 : 2;
-        if (const char *e = getenv("RT_AMD_NODE_STEPS")) steps = atoi(e) == 4 ? 4 : atoi(e) == 2 ? 2 : steps; // tuning aid
+        if (s->opt_node_steps == 2 || s->opt_node_steps == 4) steps = s->opt_node_steps; // RT_OPT_NODE_STEPS
 #define RT_LAUNCH_LANES(TEX, BOX, STEPS) \
     hipLaunchKernelGGL((render_fastlanes_kernel<TEX, BOX, STEPS>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter)
 #define RT_LAUNCH_LANES_STEPS(TEX, BOX) \
@@ -1437,14 +1452,30 @@ extern "C" int rt_trace_rays_noalloc(rt_scene *s, int32_t n, const float *h_rays
 extern "C" int rt_scene_set_option(rt_scene *s, int option, int value)
 {
     if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: null scene");
-    if (value != RT_PATH_AUTO && value != RT_PATH_EXACT && value != RT_PATH_FAST)
-        return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: value %d", value);
-    if (value == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
-        return rt_fail(RT_ERR_UNSUPPORTED, "rt_scene_set_option: the fast path cannot run this scene (%s; and no ordered walk)", s->fast_why);
-    if (option == RT_OPT_RENDER_PATH) s->render_path = value;
-    else if (option == RT_OPT_TRACE_PATH) s->trace_path = value;
-    else return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: unknown option %d", option);
-    return RT_OK;
+    if (option == RT_OPT_RENDER_PATH || option == RT_OPT_TRACE_PATH) {
+        if (value != RT_PATH_AUTO && value != RT_PATH_EXACT && value != RT_PATH_FAST)
+            return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: value %d", value);
+        if (value == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
+            return rt_fail(RT_ERR_UNSUPPORTED, "rt_scene_set_option: the fast path cannot run this scene (%s; and no ordered walk)", s->fast_why);
+        (option == RT_OPT_RENDER_PATH ? s->render_path : s->trace_path) = value;
+        return RT_OK;
+    }
+    if (value < 0) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: option %d value %d", option, value);
+    switch (option) {
+    case RT_OPT_BLOCK_KERNEL: s->opt_block_kernel = value != 0; return RT_OK;
+    case RT_OPT_CHAIN_TASKS: s->opt_chain = value != 0; return RT_OK;
+    case RT_OPT_TARGET_TASKS: s->opt_target_tasks = value; return RT_OK;
+    case RT_OPT_PATHS_PER_LANE: s->opt_paths_per_lane = value; return RT_OK;
+    case RT_OPT_NODE_STEPS:
+        if (value != 0 && value != 2 && value != 4) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: node steps are 2 or 4 (0: default)");
+        s->opt_node_steps = value;
+        return RT_OK;
+    case RT_OPT_CHAIN_BLOCKS_PER_CU:
+        if (value > 64) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: at most 64 blocks per CU");
+        s->opt_chain_blocks_per_cu = value;
+        return RT_OK;
+    }
+    return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: unknown option %d", option);
 }
 
 extern "C" int rt_scene_get_info(rt_scene *s, int what, int *value)
@@ -1454,6 +1485,7 @@ extern "C" int rt_scene_get_info(rt_scene *s, int what, int *value)
     case RT_INFO_FAST_PATH_AVAILABLE: *value = (s->fast_ok || s->lanes_ok) ? 1 : 0; return RT_OK;
     case RT_INFO_LAST_RENDER_PATH: *value = s->last_render_path; return RT_OK;
     case RT_INFO_RECORDS: *value = s->fast_ok ? s->layout.lights_base + s->layout.n_lights : -1; return RT_OK;
+    case RT_INFO_BVH_LEVELS: *value = s->lanes_ok ? s->bvh_levels : 0; return RT_OK;
     }
     return rt_fail(RT_ERR_INVALID, "rt_scene_get_info: unknown item %d", what);
 }

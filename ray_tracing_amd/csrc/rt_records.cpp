@@ -72,7 +72,7 @@ int emit_lights(const rt_scene_desc *d, rt_record_table *out, int at)
 
 } // namespace
 
-extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, const char **why)
+extern "C" int rt_records_build(const rt_scene_desc *d, int keep_boxes, rt_record_table *out, const char **why)
 {
     static const char *ok = "";
     *why = ok;
@@ -102,8 +102,8 @@ extern "C" int rt_records_build(const rt_scene_desc *d, rt_record_table *out, co
             const rt_prim &p = d->prims[d->entries[e].a];
             n_leaf_records += p.kind == RT_PRIM_GROUP && !rt_as_box(d, p, box_lo, box_hi, box_face) ? p.count : 1;
         }
-    // (RT_AMD_RECORDS_KEEP_BOXES: test aid -- small scenes keep their box records too, so the tests reach the generic scan)
-    const bool keep_inner = n_leaf_records > RT_REC_FLAT_LEAVES || getenv("RT_AMD_RECORDS_KEEP_BOXES") != nullptr;
+    // (keep_boxes: test aid -- small scenes keep their box records too, so the tests reach the generic scan)
+    const bool keep_inner = n_leaf_records > RT_REC_FLAT_LEAVES || keep_boxes != 0;
     for (int e = 0; e < d->n_entries; ++e) {
         map[e] = n_stream;
         const rt_entry &en = d->entries[e];

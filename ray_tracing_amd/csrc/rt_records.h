@@ -89,8 +89,9 @@ extern "C" {
 /* Builds the table from a validated description.  Returns 1 if the scene fits
  * (<= 64 records, only spheres / rects / boxes / flat lists, no media, no moving
  * spheres, no texture that needs (u,v)), 0 if it does not (the caller then uses
- * the generic memory-resident path).  `why` receives a short reason. */
-int rt_records_build(const rt_scene_desc *d, rt_record_table *out, const char **why);
+ * the generic memory-resident path).  `why` receives a short reason.  keep_boxes: small scenes keep their inner
+ * (box) records too (RT_CREATE_KEEP_BOX_RECORDS). */
+int rt_records_build(const rt_scene_desc *d, int keep_boxes, rt_record_table *out, const char **why);
 /* Lights only (n_stream = 0): for scenes that do not fit.  Returns 0 if there are more than 64 lights. */
 int rt_records_build_lights(const rt_scene_desc *d, rt_record_table *out);
 #ifdef __cplusplus

@@ -1,6 +1,7 @@
 // rt_host.cpp -- C entry points of the host scene layer (include/rt_host.h)
 #include "../../include/rt_host.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -16,25 +17,40 @@
 // Texels of the earth texture (reference: stbi_load("../data/earth.jpg"), src/scenes.h:296).  JPEG decoding is host
 // I/O outside the hot path; the product ships the decoded 1024x512 RGB pixels (ray_tracing_amd/data/, written by
 // `oracle/_ref/ref_harness earth`, i.e. decoded by the reference's own stb_image) and reads them from beside the library.
+static std::string g_earth_problem; // why rt_ext_earth_pixels returned nullptr (rt_host_scene_build reports it)
 unsigned char *rt_ext_earth_pixels(int *nx, int *ny)
 {
     static std::vector<unsigned char> px;
     if (px.empty()) {
-        Dl_info info;
-        std::string dir = ".";
-        if (dladdr((void *)&rt_ext_earth_pixels, &info) && info.dli_fname) {
-            dir = info.dli_fname;
-            size_t slash = dir.find_last_of('/');
-            dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+        // RT_AMD_DATA_DIR names the directory that holds earth_1024x512.rgb; default: data/ beside the library
+        std::string dir;
+        if (const char *e = getenv("RT_AMD_DATA_DIR")) {
+            dir = e;
+        } else {
+            Dl_info info;
+            dir = ".";
+            if (dladdr((void *)&rt_ext_earth_pixels, &info) && info.dli_fname) {
+                dir = info.dli_fname;
+                size_t slash = dir.find_last_of('/');
+                dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+            }
+            dir += "/data";
         }
-        std::string path = dir + "/data/earth_1024x512.rgb";
+        const std::string path = dir + "/earth_1024x512.rgb";
         if (FILE *f = fopen(path.c_str(), "rb")) {
             px.resize((size_t)3 * 1024 * 512);
-            if (fread(px.data(), 1, px.size(), f) != px.size()) px.clear();
+            const size_t got = fread(px.data(), 1, px.size(), f);
+            const bool more = got == px.size() && fgetc(f) != EOF;
             fclose(f);
+            if (got != px.size() || more) {
+                px.clear();
+                g_earth_problem = path + " is not 1024 x 512 x 3 bytes (a text-mode checkout can do that: it is binary data)";
+            }
+        } else {
+            g_earth_problem = "cannot open " + path + " (the decoded earth texture; set RT_AMD_DATA_DIR to the directory that holds it)";
         }
     }
-    if (px.empty()) return nullptr; // the scene is then built without the textured sphere
+    if (px.empty()) return nullptr; // rt_host_scene_build fails with g_earth_problem: no scene is built without its texture
     *nx = 1024, *ny = 512;
     return px.data();
 }
@@ -86,7 +102,10 @@ extern "C" int rt_host_scene_build(const char *name, float aspect, rt_host_scene
     rt_host_rng_instance().reset(); // a fresh process, as far as RAN01() is concerned
     hitable *world = nullptr, *important = nullptr;
     camera *cam = nullptr;
+    g_earth_problem.clear();
     fn(&world, &important, &cam, aspect);
+    // a scene that asked for the earth texture and did not get it is not the scene of that name: fail, loudly
+    if (!g_earth_problem.empty()) return rt_fail(RT_ERR_INVALID, "rt_host_scene_build('%s'): %s", name, g_earth_problem.c_str());
     // src/main.cpp:508-511: the BVH is always built over the list the scene function returns
     hitable_list *wl = static_cast<hitable_list *>(world);
     bvh_node *root = new bvh_node(wl->list, wl->list_size, 0.0f, 1.0f);

@@ -27,7 +27,7 @@ int main(int argc, char **argv)
         const rt_scene_desc *d = rt_host_scene_desc(h);
         rt_record_table t;
         const char *why = "";
-        const int fits = rt_records_build(d, &t, &why);
+        const int fits = rt_records_build(d, 0, &t, &why);
         int bad = 0, boxes = 0, rects = 0, spheres = 0;
         if (fits) {
             std::set<int> ids;

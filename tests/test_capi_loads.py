@@ -60,3 +60,36 @@ def test_scene_description_is_validated_before_any_device_work(cornell_host):
     d = _capi.rt_scene_desc.from_buffer_copy(cornell_host.desc.contents)
     d.n_lights = 0
     assert lib.rt_scene_create(C.byref(d), 0, C.byref(out)) == _capi.RT_ERR_INVALID
+
+
+def test_descriptions_on_which_the_render_paths_would_disagree_are_rejected(cornell_host):
+    """A light under an instance chain (translate / rotate_y do not forward pdf_value / random, src/hitable.h:19-20: the
+    flattener passes -1 for it) and a list member whose chain differs from its list's: the exact, record-table and per-lane
+    paths would each read such a description differently, so rt_scene_create refuses it."""
+    lib = _capi.load()
+    out = C.c_void_p()
+    src = cornell_host.desc.contents
+
+    def copy_with_prims():
+        d = _capi.rt_scene_desc.from_buffer_copy(src)
+        prims = (_capi.rt_prim * d.n_prims)(*[d.prims[i] for i in range(d.n_prims)])
+        d.prims = prims
+        return d, prims
+
+    assert src.n_chains >= 2  # the tall box sits under translate(rotate_y(...))
+    d, prims = copy_with_prims()
+    light = [src.lights[i] for i in range(src.n_lights) if src.lights[i] >= 0][0]
+    prims[light].chain = 1
+    assert lib.rt_scene_create(C.byref(d), 0, C.byref(out)) == _capi.RT_ERR_INVALID
+    assert b"instance chain" in lib.rt_last_error()
+
+    d, prims = copy_with_prims()
+    group = [i for i in range(src.n_prims) if src.prims[i].kind == _capi.RT_PRIM_GROUP and src.prims[i].chain != 0][0]
+    prims[prims[group].first + 2].chain = 0
+    assert lib.rt_scene_create(C.byref(d), 0, C.byref(out)) == _capi.RT_ERR_INVALID
+    assert b"its group chain" in lib.rt_last_error()
+
+    d = _capi.rt_scene_desc.from_buffer_copy(src)
+    lights = (C.c_int32 * d.n_lights)(*([-2] * d.n_lights))
+    d.lights = lights
+    assert lib.rt_scene_create(C.byref(d), 0, C.byref(out)) == _capi.RT_ERR_INVALID
