@@ -28,6 +28,19 @@ namespace rtf {
 
 RTF_DEV V3 rcp3(V3 d) { return v3(rcp(d.x), rcp(d.y), rcp(d.z)); }
 
+// b and the discriminant of sphere::hit (src/sphere.h:26-32) with the reference's operations one by one (products and sums
+// rounded separately, in its order).  WHETHER a ray hits a small sphere far away is decided by the sign of b*b - a*c, a
+// difference of two numbers that agree in their first five or six digits (a sphere of radius 0.25 seen from 200 units
+// away): with fused operations the sign comes out differently on a few per cent of the grazing rays -- no less valid, but
+// not the reference's answer (the 1M-sphere scene: 1.7 % of camera rays found another sphere).  The roots themselves keep
+// the hardware-rate sqrt and reciprocal: an ulp in t only matters where two surfaces coincide.
+RTF_DEV void sphere_disc(V3 oc, V3 d, float dd, float radius, float &b, float &disc)
+{
+    b = ref_dot(oc, d);
+    const float cc = sub_rn(ref_dot(oc, oc), mul_rn(radius, radius));
+    disc = sub_rn(mul_rn(b, b), mul_rn(dd, cc));
+}
+
 // sphere / moving_sphere / rect in its own space: t only.  src/sphere.h:21-59, 147-183; src/plane.h:9-29, 47-67, 109-129
 RTF_DEV bool plain_t(const rt_prim &pr, const Ray &lr, V3 inv, float dd, float inv_dd, float t_min, float t_max, float &t)
 {
@@ -44,9 +57,8 @@ RTF_DEV bool plain_t(const rt_prim &pr, const Ray &lr, V3 inv, float dd, float i
             radius = pr.f[6];
         }
         const V3 oc = v3(lr.o.x - c.x, lr.o.y - c.y, lr.o.z - c.z);
-        const float b = fdot(oc, lr.d);
-        const float cc = fmaf(-radius, radius, fdot(oc, oc));
-        const float disc = fmaf(b, b, -(dd * cc));
+        float b, disc;
+        sphere_disc(oc, lr.d, dd, radius, b, disc);
         const float sq = fsqrt(disc);
         const float t1 = (-b - sq) * inv_dd, t2 = (-b + sq) * inv_dd;
         const bool in1 = (t1 < t_max) & (t1 > t_min), in2 = (t2 < t_max) & (t2 > t_min);
@@ -120,7 +132,7 @@ RTF_DEV void walk_start(Walk &w, const Ray &wr, float t_max, bool go)
     w.best_prim = -1;
     w.winv = rcp3(wr.d);
     w.noi = v3(-wr.o.x * w.winv.x, -wr.o.y * w.winv.y, -wr.o.z * w.winv.z);
-    w.dd = fdot(wr.d, wr.d);
+    w.dd = ref_dot(wr.d, wr.d); // as src/sphere.h:27 rounds it: it enters the sign of the discriminant (sphere_disc)
     w.inv_dd = rcp(w.dd);
 }
 RTF_DEV int walk_pop(Walk &w, const int *stack) { return w.sp > 0 ? stack[--w.sp * 64] : RT_BVH_NONE; }
@@ -179,9 +191,8 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
     if (kind == RT_PRIM_SPHERE) { // src/sphere.h:21-59
         const V3 oc = v3(lr.o.x - __uint_as_float(la.x), lr.o.y - __uint_as_float(la.y), lr.o.z - __uint_as_float(la.z));
         const float radius = __uint_as_float(la.w);
-        const float b = fdot(oc, lr.d);
-        const float cc = fmaf(-radius, radius, fdot(oc, oc));
-        const float disc = fmaf(b, b, -(w.dd * cc));
+        float b, disc;
+        sphere_disc(oc, lr.d, w.dd, radius, b, disc);
         const float sq = fsqrt(disc);
         const float t1 = (-b - sq) * w.inv_dd, t2 = (-b + sq) * w.inv_dd;
         const bool in1 = (t1 < w.best_t) & (t1 > t_min), in2 = (t2 < w.best_t) & (t2 > t_min);
