@@ -558,17 +558,25 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
             if (lane == 0) n_old[wave] = n;
         }
         __syncthreads();
-        int before = 0, n_dead = 0; // slots of lower classes + slots of my class in lower waves
+        // Slots: the specular lanes first, then as many of the dead lanes as it takes to fill their last wave, then the
+        // diffuse lanes (rect light, then axis sampling), then the other dead lanes.  The padding keeps specular and diffuse
+        // lanes out of each other's waves: a wave that holds both runs both scatter functions, each with part of its lanes.
+        int tot0 = 0, tot1 = 0, tot2 = 0, n_dead = 0, low = 0; // class totals; lanes of my class in lower waves
 #pragma unroll
         for (int w2 = 0; w2 < NW; ++w2) {
             const int4 n = cnt[w2];
-            const int lower = (cls > 0 ? n.x : 0) + (cls > 1 ? n.y : 0) + (cls > 2 ? n.z : 0);
             const int same = cls == 0 ? n.x : cls == 1 ? n.y : cls == 2 ? n.z : n.w;
-            before += lower + (w2 < wave ? same : 0);
-            n_dead += n.w;
+            tot0 += n.x, tot1 += n.y, tot2 += n.z, n_dead += n.w;
+            low += w2 < wave ? same : 0;
         }
+#ifdef RT_NO_SPEC_PADDING
+        const int pad = 0;
+#else
+        const int pad = min(n_dead, (64 - (tot0 & 63)) & 63);
+#endif
         const unsigned pool_now = pool_next; // stable between the two barriers: only the refill changes it
-        const int dst = before + rank;
+        const int g = low + rank;
+        const int dst = cls == 0 ? g : cls == 1 ? tot0 + pad + g : cls == 2 ? tot0 + pad + tot1 + g : g < pad ? tot0 + g : tot0 + tot1 + tot2 + g;
         // (the ray's time is not carried: nothing the record table can hold -- static spheres and rects -- reads it)
         const uint32_t packed = (uint32_t)depth | ((uint32_t)pix << 16) | ((uint32_t)cls << 25) | ((uint32_t)to_light << 27) | ((uint32_t)light << 28);
         xch[0][dst] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(d.x));
@@ -727,6 +735,12 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 #ifndef RT_LANES_WAVES_PER_EU
 #define RT_LANES_WAVES_PER_EU 6
 #endif
+#ifdef RT_COUNT_WALK // development (tools/work_counts.py): what the walks of a launch touch -- the algorithmic bytes of the roofline
+__device__ unsigned long long g_walk_counts[4]; // node steps (one 32-byte node each), leaf tests (one 32-byte leaf each), rays, paths
+#define RT_COUNT(k, cond) n_count[k] += (cond) ? 1u : 0u
+#else
+#define RT_COUNT(k, cond)
+#endif
 template <bool TEX, bool BOX, int STEPS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 __attribute__((amdgpu_waves_per_eu(RT_LANES_WAVES_PER_EU, RT_LANES_WAVES_PER_EU)))
@@ -766,6 +780,9 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     int depth = 0, pix = lane;
     rtf::Walk w;
     rtf::walk_start(w, r, RT_FLT_MAX, false);
+#ifdef RT_COUNT_WALK
+    unsigned n_count[4] = {0u, 0u, 0u, 0u};
+#endif
 
     for (;;) {
         // ---- lanes whose walk is over: shade, refill, start the next walk ----------------------
@@ -832,10 +849,12 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                         depth = 0;
                         alive = true;
                         fresh = true;
+                        RT_COUNT(3, true);
                     }
                 }
                 next += __popcll(dead);
             }
+            RT_COUNT(2, fresh);
             if (fresh) rtf::walk_start(w, r, RT_FLT_MAX, true);
             if (!__any(alive)) {
                 if (next >= total) break;
@@ -844,15 +863,21 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
         }
         // ---- the walks ------------------------------------------------------------------------------
 #pragma unroll
-        for (int step = 0; step < STEPS; ++step)
+        for (int step = 0; step < STEPS; ++step) {
+            RT_COUNT(0, w.cur >= 0);
             if (w.cur >= 0) rtf::walk_node(S, w, 0.001f, stack);
+        }
         const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
         if (__popcll(__ballot(at_leaf)) >= RT_LEAF_BATCH || !__any(w.cur >= 0)) {
+            RT_COUNT(1, at_leaf);
             if (at_leaf) rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
         }
     }
 
     flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
+#ifdef RT_COUNT_WALK
+    for (int k = 0; k < 4; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
+#endif
 }
 
 __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n, const float *__restrict__ rays, float t_min, float t_max,
@@ -1477,6 +1502,19 @@ extern "C" int rt_scene_set_option(rt_scene *s, int option, int value)
     }
     return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: unknown option %d", option);
 }
+
+#ifdef RT_COUNT_WALK
+// development builds only (tools/work_counts.py): node steps, leaf tests, rays and paths of the per-lane kernels since the last reset
+extern "C" int rt_debug_walk_counts(unsigned long long *out4, int reset)
+{
+    void *p = nullptr;
+    RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_walk_counts)));
+    RT_HIP(hipDeviceSynchronize());
+    if (out4) RT_HIP(hipMemcpy(out4, p, 32, hipMemcpyDeviceToHost));
+    if (reset) RT_HIP(hipMemset(p, 0, 32));
+    return RT_OK;
+}
+#endif
 
 extern "C" int rt_scene_get_info(rt_scene *s, int what, int *value)
 {

@@ -250,10 +250,23 @@ RTF_DEV void stage_records(const uint32_t *__restrict__ recs, uint32_t *lrecs, i
 RTF_DEV void rect_run(const uint32_t *lrecs, int &index, int count, float t_min, float ok, float dk, float ik, float oa, float da,
                       float ob, float db, Best &best)
 {
-    for (int k = 0; k < count; ++k, ++index) {
-        const LRec c = lds_rec(lrecs, index);
-        rect_update_v(__uint_as_float(c.kk.y), c.kk.x, __uint_as_float(c.a.x), __uint_as_float(c.a.y), __uint_as_float(c.a.z),
-                      __uint_as_float(c.a.w), t_min, ok, dk, ik, oa, da, ob, db, best);
+    // Two records per turn, each read while the other is tested (the table is padded: reading one record past the run is
+    // harmless).  Written out by hand: a rotating "next record" variable costs four register moves per record.
+    if (count == 0) return;
+    LRec a = lds_rec(lrecs, index);
+    int k = 0;
+    for (; k + 2 <= count; k += 2, index += 2) {
+        const LRec b = lds_rec(lrecs, index + 1);
+        rect_update_v(__uint_as_float(a.kk.y), a.kk.x, __uint_as_float(a.a.x), __uint_as_float(a.a.y), __uint_as_float(a.a.z),
+                      __uint_as_float(a.a.w), t_min, ok, dk, ik, oa, da, ob, db, best);
+        a = lds_rec(lrecs, index + 2);
+        rect_update_v(__uint_as_float(b.kk.y), b.kk.x, __uint_as_float(b.a.x), __uint_as_float(b.a.y), __uint_as_float(b.a.z),
+                      __uint_as_float(b.a.w), t_min, ok, dk, ik, oa, da, ob, db, best);
+    }
+    if (k < count) {
+        rect_update_v(__uint_as_float(a.kk.y), a.kk.x, __uint_as_float(a.a.x), __uint_as_float(a.a.y), __uint_as_float(a.a.z),
+                      __uint_as_float(a.a.w), t_min, ok, dk, ik, oa, da, ob, db, best);
+        ++index;
     }
 }
 

@@ -6,7 +6,7 @@ tag=$1; shift
 cd "$(dirname "$0")/../ray_tracing_amd"
 make -s librt_amd.so
 mkdir -p build_var/data && cp -u data/earth_1024x512.rgb build_var/data/
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function \
     -Wno-bitwise-instead-of-logical "$@" -c csrc/rt_amd.hip -o build_var/rt_amd_$tag.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build_var/rt_amd_$tag.o build/rt_error.o build/rt_records.o build/rt_order.o \
     build/rt_bvh.o build/rt_host.o build/rt_flatten.o -ldl -o build_var/librt_$tag.so
