@@ -153,6 +153,7 @@ def parse_args(argv):
     ap.add_argument("--spp", type=int, default=None, help=argparse.SUPPRESS)  # for quick experiments only
     ap.add_argument("--size", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--rehearse-rccl", action="store_true", help=argparse.SUPPRESS)  # see main()
     return ap.parse_args(argv)
 
 
@@ -183,9 +184,12 @@ def main(argv=None):
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    # --rehearse-rccl: a one-rank process group and the reduce issued on it (started by torch.distributed.run with
+    # --nproc-per-node 1): the RCCL initialisation and collective of the N > 1 path executed on a one-GPU box
+    grouped = world > 1 or (a.rehearse_rccl and "RANK" in os.environ)
+    if grouped:
         dist.init_process_group(backend, **({} if hook else {"device_id": dev}))
-    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    n_ranks_seen = dist.get_world_size() if grouped else 1
 
     cfg = dict(CONFIGS[a.config])
     nx = ny = None
@@ -223,13 +227,13 @@ def main(argv=None):
 
     def step():
         acc = render(s0, s1)
-        D.reduce_accumulators(acc, 0)
+        D.reduce_accumulators(acc, 0, even_alone=grouped)
         if rank == 0:
             resolve(acc)
 
     def fence():
         sync()
-        if world > 1:
+        if grouped:
             dist.barrier()
         sync()
 
@@ -244,7 +248,7 @@ def main(argv=None):
     # kernel duration from the HIP events rt_render records on its launch stream (last step; steps are identical)
     k_ms = last_ms()
     t = torch.tensor([dt, k_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, k_ms = float(t[0]), float(t[1])
 
@@ -264,7 +268,7 @@ def main(argv=None):
             peak, unit = FP32_VECTOR_PEAK_TFLOPS, "TFLOP/s"
             note = "no dense contraction on this path: MFMA unused, FP32 vector peak = FP32 matrix peak"
         partition = (f"disjoint spp ranges over {world} GPUs + one RCCL sum-reduce of float4[{nx}*{ny}] onto rank 0" if world > 1 else
-                     "one GPU renders every sample; no reduce at N=1")
+                     "one GPU renders every sample; no reduce at N=1" + (" (rehearsal: a one-rank RCCL reduce per step)" if grouped else ""))
         out = {
             "metric": "Mpaths/sec (node), Cornell box 1024x1024 1024spp depth 50" if a.config == "c2" else
                       f"Mpaths/sec (node), {cfg['scene']} {cfg['nx']}x{cfg['ny']} {cfg['spp']}spp depth {DEPTH}",
@@ -281,7 +285,7 @@ def main(argv=None):
         if world == 1 and not a.no_cpu and not hook:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -217,6 +217,22 @@ int rt_resolve(const float* d_accum, int32_t nx, int32_t ny, uint32_t* d_rgba8, 
 int rt_render_to_host(rt_scene* scene, const rt_render_params* params, float* h_accum,
                       uint32_t* h_rgba8);
 
+/* Samples [*begin, *end) of GPU `rank` of `world` out of [sample_begin, sample_end): the ranges of all ranks tile the
+ * budget, sizes differ by at most one.  This is the partition of src/main.cpp:543-557 (one task per sample) cut into
+ * `world` contiguous pieces.  No device needed. */
+int rt_sample_range(int32_t rank, int32_t world, int32_t sample_begin, int32_t sample_end, int32_t* begin, int32_t* end);
+
+/* One image on several GPUs of one node, from one host process (no Python, no launcher): a scene is created on every
+ * device of `devices`, device i renders the samples rt_sample_range(i, n_devices, ...) gives it (all devices at once,
+ * one stream each), the float4 sums are added onto devices[0] with ONE RCCL sum-reduce over xGMI (ncclReduce, float,
+ * 4*nx*ny elements), and devices[0] resolves.  Replaces thread_pool + the per-sample sum of src/main.cpp:523-561,
+ * 720-726 for a multi-GPU node.  h_accum: host float[ny][nx][4] sums; h_rgba8: host uint32[ny][nx] or NULL.  Blocking.
+ * RCCL (librccl.so.1) is opened at run time; without it the call fails with RT_ERR_UNSUPPORTED when n_devices > 1.
+ * RT_MULTI_REDUCE_ALWAYS: run the reduce also on ONE device (a one-rank communicator): exercises the RCCL path. */
+#define RT_MULTI_REDUCE_ALWAYS 1u
+int rt_render_multi_to_host(const rt_scene_desc* desc, const int32_t* devices, int32_t n_devices,
+                            const rt_render_params* params, uint32_t flags, float* h_accum, uint32_t* h_rgba8);
+
 /* ------------------------------------------------------------------ */
 /* Closest-hit queries (the parity surface)                             */
 /* ------------------------------------------------------------------ */

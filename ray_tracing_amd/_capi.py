@@ -20,6 +20,7 @@ RT_OPT_RENDER_PATH, RT_OPT_TRACE_PATH = 1, 2
 (RT_OPT_BLOCK_KERNEL, RT_OPT_CHAIN_TASKS, RT_OPT_TARGET_TASKS, RT_OPT_PATHS_PER_LANE, RT_OPT_NODE_STEPS,
  RT_OPT_CHAIN_BLOCKS_PER_CU) = range(3, 9)
 RT_CREATE_KEEP_BOX_RECORDS = 1
+RT_MULTI_REDUCE_ALWAYS = 1
 RT_PATH_AUTO, RT_PATH_EXACT, RT_PATH_FAST = 0, 1, 2
 RT_INFO_FAST_PATH_AVAILABLE, RT_INFO_LAST_RENDER_PATH, RT_INFO_RECORDS, RT_INFO_BVH_LEVELS = 1, 2, 3, 4
 
@@ -102,6 +103,9 @@ PROTOTYPES = {
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(rt_render_params), C.c_void_p, C.c_void_p]),
     "rt_resolve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "rt_render_to_host": (C.c_int, [C.c_void_p, C.POINTER(rt_render_params), C.c_void_p, C.c_void_p]),
+    "rt_sample_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rt_render_multi_to_host": (C.c_int, [C.POINTER(rt_scene_desc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(rt_render_params),
+                                          C.c_uint32, C.c_void_p, C.c_void_p]),
     "rt_camera_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "rt_trace_rays_noalloc": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),

@@ -14,6 +14,7 @@
 //     (src/main.cpp:270-326) from rt_camera_rays + rt_trace_rays at pixel centres; the reference's own -p
 //     dumps buffers it never fills;
 //   * extra options, absent from the reference: --scene NAME, --seed N, --device N, --path auto|exact|fast, and
+//     --devices LIST [--reduce-always] (the samples shared by several GPUs of the node, one RCCL sum-reduce), and
 //     --accum FILE [--save-every N]: progressive render with save and resume, which the reference lists as not done
 //     (TODO.txt:5-17).  The file holds the float sums and the number of samples in them; -s is the TOTAL wanted.
 // No CPU rendering path exists here: without a HIP device the program stops with the library's error.
@@ -69,6 +70,8 @@ Opt g_opts[] = {
     {"", "path", "auto | exact | fast", true, "auto", nullptr, "", 0},
     {"", "accum", "Accumulator file: resume from it if it exists, save to it", true, "", nullptr, "", 0},
     {"", "save-every", "With --accum: also save after every N samples", false, "0", nullptr, "", 0},
+    {"", "devices", "GPUs that share the samples, e.g. 0-7 or 0,2,5 (one RCCL sum-reduce onto the first)", true, "", nullptr, "", 0},
+    {"", "reduce-always", "With --devices: run the RCCL reduce on one device too", false, "0", "1", "", 0},
 };
 const int g_nopts = sizeof(g_opts) / sizeof(g_opts[0]);
 
@@ -350,15 +353,41 @@ int main(int argc, char **argv)
         die("--save-every needs --accum");
     }
 
+    // --devices: "0-7", "0,2,5", "3"
+    std::vector<int32_t> devices;
+    if (!opt_str("devices").empty()) {
+        const std::string &d = opt_str("devices");
+        size_t at = 0;
+        while (at < d.size()) {
+            char *end = nullptr;
+            long a = strtol(d.c_str() + at, &end, 10), b = a;
+            if (end == d.c_str() + at || a < 0) die("--devices takes a list like 0-7 or 0,2,5");
+            at = (size_t)(end - d.c_str());
+            if (at < d.size() && d[at] == '-') {
+                b = strtol(d.c_str() + at + 1, &end, 10);
+                if (end == d.c_str() + at + 1 || b < a) die("--devices takes a list like 0-7 or 0,2,5");
+                at = (size_t)(end - d.c_str());
+            }
+            for (long k = a; k <= b && devices.size() < 64; ++k) devices.push_back((int32_t)k);
+            if (at < d.size()) {
+                if (d[at] != ',') die("--devices takes a list like 0-7 or 0,2,5");
+                ++at;
+            }
+        }
+        if (devices.empty()) die("--devices names no device");
+        if (separate || !accum_file.empty() || passes) die("--devices does not go together with -m, -p or --accum");
+    }
+
     // scene and camera setup, src/main.cpp:499-511
     rt_host_scene *host = nullptr;
     check(rt_host_scene_build(opt_str("scene").c_str(), float(nx) / float(ny), &host), "scene");
     rt_scene *scene = nullptr;
-    check(rt_scene_create(rt_host_scene_desc(host), opt_int("device"), &scene), "rt_scene_create");
+    if (devices.empty()) check(rt_scene_create(rt_host_scene_desc(host), opt_int("device"), &scene), "rt_scene_create");
     const std::string &path = opt_str("path");
     int path_id = path == "auto" ? RT_PATH_AUTO : path == "exact" ? RT_PATH_EXACT : path == "fast" ? RT_PATH_FAST : -1;
     if (path_id < 0) die("--path takes auto, exact or fast");
-    check(rt_scene_set_option(scene, RT_OPT_RENDER_PATH, path_id), "--path");
+    if (scene) check(rt_scene_set_option(scene, RT_OPT_RENDER_PATH, path_id), "--path");
+    if (!devices.empty() && path_id != RT_PATH_AUTO) die("--devices renders on the path the library picks (--path auto)");
 
     auto time_start = std::chrono::high_resolution_clock::now();
 
@@ -438,6 +467,13 @@ int main(int argc, char **argv)
             }
             image[k] = pack(c[0], c[1], c[2]);
         }
+    } else if (!devices.empty()) {
+        // the samples shared by several GPUs: disjoint sample ranges, one RCCL sum-reduce, resolve on the first (include/rt_amd.h)
+        rp.sample_begin = 0, rp.sample_end = ns;
+        check(rt_render_multi_to_host(rt_host_scene_desc(host), devices.data(), (int32_t)devices.size(), &rp,
+                                      opt_int("reduce-always") ? RT_MULTI_REDUCE_ALWAYS : 0u, accum.data(), image.data()),
+              "rt_render_multi_to_host");
+        printf("%d/%d : %.2f%%\r", ns, ns, 100.0f);
     } else {
         rp.sample_begin = 0, rp.sample_end = ns;
         check(rt_render_to_host(scene, &rp, accum.data(), image.data()), "rt_render");
@@ -492,7 +528,7 @@ int main(int argc, char **argv)
     printf("Writing file.\n");
     if (!write_png(out_filename, nx, ny, image.data())) die("cannot write " + out_filename);
 
-    rt_scene_destroy(scene);
+    if (scene) rt_scene_destroy(scene);
     rt_host_scene_free(host);
     return 0;
 }

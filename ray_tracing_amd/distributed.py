@@ -16,9 +16,10 @@ def sample_range(rank, world, spp):
     return rank * spp // world, (rank + 1) * spp // world
 
 
-def reduce_accumulators(accum, dst=0, group=None):
-    """Sum the [A,B,G,R] accumulators of all ranks onto `dst` (in place there).  A no-op without a process group."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def reduce_accumulators(accum, dst=0, group=None, even_alone=False):
+    """Sum the [A,B,G,R] accumulators of all ranks onto `dst` (in place there).  A no-op without a process group or with a
+    single rank (even_alone=True issues the collective on a one-rank group too: a rehearsal of the RCCL path on one GPU)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or even_alone):
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum
 

@@ -165,3 +165,39 @@ def test_single_call_render_equals_the_api(tmp_path):
     d = np.abs(got.view(np.uint8).astype(int) - rgba.view(np.uint8).astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 0.01  # float atomics may reorder sums between two runs
     sc.close()
+
+
+@pytest.mark.gpu
+def test_native_multi_device_render_with_rccl_on_one_device(tmp_path):
+    """rt_render_multi_to_host / `raytracer --devices 0 --reduce-always`: the one-process multi-GPU path (a scene, a stream and
+    an accumulator per device, disjoint sample ranges, ONE RCCL sum-reduce onto the first device, resolve there).  This box
+    has one GPU, so the device list is degenerate, but everything runs: librccl is opened, a communicator is made, the
+    reduce is issued on the render stream.  The image must equal rt_render_to_host's (same paths, same sums)."""
+    import ctypes as C
+    from ray_tracing_amd import _capi, api
+    lib = _capi.load()
+    nx, ny, ns = 64, 40, 12
+    hs = api.HostScene("cornell_box", nx / ny)
+    sc = api.Scene(hs, 0)
+    want_acc, want_img = api.render_to_host(sc, nx, ny, 0, ns, seed=4)
+    sc.close()
+    p = api.make_params(nx, ny, 0, ns, seed=4)
+    acc = np.zeros((ny, nx, 4), np.float32)
+    img = np.zeros((ny, nx), np.uint32)
+    dev = (C.c_int32 * 1)(0)
+    for flags in (0, _capi.RT_MULTI_REDUCE_ALWAYS):
+        acc[:] = 0
+        st = lib.rt_render_multi_to_host(hs.desc, dev, 1, C.byref(p), flags, acc.ctypes.data_as(C.c_void_p), img.ctypes.data_as(C.c_void_p))
+        assert st == _capi.RT_OK, lib.rt_last_error()
+        assert np.all(acc[..., 0] == ns)
+        assert np.allclose(acc, want_acc, rtol=1e-5, atol=1e-6)
+        assert (img == want_img).mean() > 0.999
+    # the executable: same pixels as the single-device run
+    a, b = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    common = ["-w", str(nx), "-h", str(ny), "-s", str(ns), "-r", "50", "--seed", "4"]
+    pa = run(common + ["-o", a])
+    pb = run(common + ["-o", b, "--devices", "0", "--reduce-always"])
+    assert pa.returncode == 0 and pb.returncode == 0, pa.stderr + pb.stderr
+    assert (read_png(a) == read_png(b)).mean() > 0.999
+    assert run(common + ["-o", b, "--devices", "0,0"]).returncode != 0
+    assert run(common + ["-o", b, "--devices", "x"]).returncode != 0

@@ -63,3 +63,35 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert np.allclose(got["accum"], full, rtol=1e-5, atol=1e-6)  # same paths, float sums in another order
     same = (got["image"] == O.resolve(full)).mean()
     assert same > 0.99
+
+
+def test_native_sample_range_equals_the_python_partition():
+    """rt_sample_range (what rt_render_multi_to_host and `raytracer --devices` split the budget with) tiles any sample
+    range exactly and agrees with ray_tracing_amd.distributed.sample_range."""
+    import ctypes as C
+    from ray_tracing_amd import _capi
+    lib = _capi.load()
+    b, e = C.c_int32(), C.c_int32()
+    for world in (1, 2, 3, 4, 8, 64):
+        for s0, s1 in ((0, 0), (0, 1), (0, 5), (3, 11), (0, 1024), (100, 16384 + 100)):
+            got = []
+            for g in range(world):
+                assert lib.rt_sample_range(g, world, s0, s1, C.byref(b), C.byref(e)) == _capi.RT_OK
+                got.append((b.value, e.value))
+                pb, pe = D.sample_range(g, world, s1 - s0)
+                assert (b.value - s0, e.value - s0) == (pb, pe)
+            assert got[0][0] == s0 and got[-1][1] == s1 and all(got[i][1] == got[i + 1][0] for i in range(world - 1))
+    assert lib.rt_sample_range(2, 2, 0, 8, C.byref(b), C.byref(e)) == _capi.RT_ERR_INVALID
+    assert lib.rt_sample_range(0, 0, 0, 8, C.byref(b), C.byref(e)) == _capi.RT_ERR_INVALID
+
+
+def test_multi_device_render_rejects_bad_device_lists(cornell_host):
+    import ctypes as C
+    from ray_tracing_amd import _capi, api
+    lib = _capi.load()
+    p = api.make_params(8, 8, 0, 2)
+    acc = np.zeros((8, 8, 4), np.float32)
+    twice = (C.c_int32 * 2)(0, 0)
+    assert lib.rt_render_multi_to_host(cornell_host.desc, twice, 2, C.byref(p), 0, acc.ctypes.data_as(C.c_void_p), None) == _capi.RT_ERR_INVALID
+    assert b"listed twice" in lib.rt_last_error()
+    assert lib.rt_render_multi_to_host(cornell_host.desc, twice, 0, C.byref(p), 0, acc.ctypes.data_as(C.c_void_p), None) == _capi.RT_ERR_INVALID
