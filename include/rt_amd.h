@@ -301,7 +301,9 @@ enum rt_option {
     RT_OPT_TARGET_TASKS = 5,        /* tasks a launch is cut into (default 262144 waves' worth) */
     RT_OPT_PATHS_PER_LANE = 6,      /* lower bound on a task's size, in paths per lane */
     RT_OPT_NODE_STEPS = 7,          /* per-lane walk: node steps between two looks at who waits (2 or 4) */
-    RT_OPT_CHAIN_BLOCKS_PER_CU = 8  /* per-lane walk: blocks per CU of the chained grid */
+    RT_OPT_CHAIN_BLOCKS_PER_CU = 8, /* per-lane walk: blocks per CU of the chained grid */
+    RT_OPT_SHADE_BATCH = 9,         /* per-lane walk: lanes whose walk is over wait until this many of a wave's 64 are */
+    RT_OPT_LEAF_BATCH = 10          /* per-lane walk: lanes standing on a leaf wait until this many do */
 };
 enum rt_path { RT_PATH_AUTO = 0, RT_PATH_EXACT = 1, RT_PATH_FAST = 2 };
 int rt_scene_set_option(rt_scene* scene, int option, int value);

@@ -18,7 +18,7 @@ RT_RENDER_ACCUMULATE = 1
 RT_TRACE_NOALLOC_MAX_RAYS = 65536
 RT_OPT_RENDER_PATH, RT_OPT_TRACE_PATH = 1, 2
 (RT_OPT_BLOCK_KERNEL, RT_OPT_CHAIN_TASKS, RT_OPT_TARGET_TASKS, RT_OPT_PATHS_PER_LANE, RT_OPT_NODE_STEPS,
- RT_OPT_CHAIN_BLOCKS_PER_CU) = range(3, 9)
+ RT_OPT_CHAIN_BLOCKS_PER_CU, RT_OPT_SHADE_BATCH, RT_OPT_LEAF_BATCH) = range(3, 11)
 RT_CREATE_KEEP_BOX_RECORDS = 1
 RT_MULTI_REDUCE_ALWAYS = 1
 RT_PATH_AUTO, RT_PATH_EXACT, RT_PATH_FAST = 0, 1, 2

@@ -57,6 +57,8 @@ struct RenderArgs {
     int32_t n_tasks;
     int32_t stack_levels;  // per-lane fast path: inner levels of the tree = levels of the LDS stacks (dynamic LDS)
     int32_t chain;         // per-lane fast path: 1 = a wave takes further tasks from the counter when its pool is empty
+    int32_t shade_batch;   // per-lane fast path: lanes whose walk is over wait until this many are (RT_SHADE_BATCH)
+    int32_t leaf_batch;    // per-lane fast path: lanes standing on a leaf wait until this many do (RT_LEAF_BATCH)
 };
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -789,7 +791,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
         const bool waiting = alive & (w.cur == RT_BVH_NONE);
         const int n_waiting = __popcll(__ballot(waiting));
         const bool walking_any = __any(w.cur != RT_BVH_NONE);
-        if (n_waiting >= RT_SHADE_BATCH || !walking_any) {
+        if (n_waiting >= A.shade_batch || !walking_any) {
             if (waiting) {
                 const bool hit_any = w.best_prim >= 0;
                 rtf::Surface sf;
@@ -868,7 +870,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
             if (w.cur >= 0) rtf::walk_node(S, w, 0.001f, stack);
         }
         const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
-        if (__popcll(__ballot(at_leaf)) >= RT_LEAF_BATCH || !__any(w.cur >= 0)) {
+        if (__popcll(__ballot(at_leaf)) >= A.leaf_batch || !__any(w.cur >= 0)) {
             RT_COUNT(1, at_leaf);
             if (at_leaf) rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
         }
@@ -940,6 +942,7 @@ struct rt_scene {
     int last_render_path = RT_PATH_EXACT;
     // rt_scene_set_option: tuning / test switches of rt_render (0 = the library's choice)
     int opt_block_kernel = 1, opt_chain = 1, opt_target_tasks = 0, opt_paths_per_lane = 0, opt_node_steps = 0, opt_chain_blocks_per_cu = 0;
+    int opt_shade_batch = 0, opt_leaf_batch = 0;
 };
 
 #define RT_HIP(call)                                                                                                   \
@@ -1300,7 +1303,15 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
         if (A.chain) RT_HIP(hipMemsetAsync(d_task_counter, 0, sizeof(unsigned), stream));
         const size_t lds = (size_t)WAVES_PER_BLOCK * s->bvh_levels * 256; // the walks' stacks
         A.stack_levels = s->bvh_levels;
+        A.shade_batch = s->opt_shade_batch > 0 ? s->opt_shade_batch : RT_SHADE_BATCH;
+        A.leaf_batch = s->opt_leaf_batch > 0 ? s->opt_leaf_batch : RT_LEAF_BATCH;
         int steps = s->bvh_levels > 20 ? 4 : 2;
+        // deep trees: shade and test leaves in smaller batches (a lane that waits is a lane that does not walk, and walks are
+        // long there); tools/batch_sweep.py: 1M spheres 1203 -> 1278 Mpaths/s at (32, 4), the others are at their best near (40, 16)
+        if (s->bvh_levels > 20) {
+            if (s->opt_shade_batch <= 0) A.shade_batch = 32;
+            if (s->opt_leaf_batch <= 0) A.leaf_batch = 4;
+        }
         if (s->opt_node_steps == 2 || s->opt_node_steps == 4) steps = s->opt_node_steps; // RT_OPT_NODE_STEPS
 #define RT_LAUNCH_LANES(TEX, BOX, STEPS) \
     hipLaunchKernelGGL((render_fastlanes_kernel<TEX, BOX, STEPS>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter)
@@ -1494,6 +1505,11 @@ extern "C" int rt_scene_set_option(rt_scene *s, int option, int value)
     case RT_OPT_NODE_STEPS:
         if (value != 0 && value != 2 && value != 4) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: node steps are 2 or 4 (0: default)");
         s->opt_node_steps = value;
+        return RT_OK;
+    case RT_OPT_SHADE_BATCH:
+    case RT_OPT_LEAF_BATCH:
+        if (value > 64) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: a batch is at most the 64 lanes of a wave");
+        (option == RT_OPT_SHADE_BATCH ? s->opt_shade_batch : s->opt_leaf_batch) = value;
         return RT_OK;
     case RT_OPT_CHAIN_BLOCKS_PER_CU:
         if (value > 64) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: at most 64 blocks per CU");
