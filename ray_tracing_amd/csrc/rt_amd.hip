@@ -387,6 +387,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
 #define RT_BLOCK_WAVES 4
 #endif
 constexpr int BLOCK_WAVES = RT_BLOCK_WAVES;
+#ifdef RT_COUNT_SHADE // development (tools/shade_counts.py): who shades in render_fast_block_kernel, per wave and round
+// [0] wave-rounds, [1] wave-rounds that scan, [2] lanes alive at the scan, [3] wave-rounds that run scatter_specular, [4] its lanes,
+// [5] wave-rounds that run scatter_lambert, [6] its lanes, [7] wave-rounds with rect-light lanes, [8] those lanes,
+// [9] wave-rounds with axis-sampling lanes, [10] those lanes, [11] wave-rounds that refill, [12] lanes refilled
+__device__ unsigned long long g_shade_counts[16];
+#endif
 // Eight waves per SIMD: the kernel needs 58 VGPRs but, left alone, 106 SGPRs, and above 100 a SIMD of this generation holds
 // seven waves.  Told to fit eight, the compiler keeps to 96 SGPRs; Cornell 1024 spp 80.6 -> 73.1 ms.
 #ifndef RT_BLOCK_WAVES_PER_EU
@@ -461,6 +467,9 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     int depth = 0, pix = tid;
     int turn = 0;
     int old = 0; // CHAIN: 1 = this lane's path belongs to the previous task
+#ifdef RT_COUNT_SHADE
+    unsigned sc[16] = {0u};
+#endif
 
     for (;;) {
         // ---- refill: dead lanes (together in the last waves after the regroup) take items from the block's pool --------
@@ -498,6 +507,14 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
             }
         }
 
+#ifdef RT_COUNT_SHADE
+        {
+            const int na = __popcll(__ballot(alive)), nd = __popcll(dead);
+            sc[0] += 1u, sc[1] += na > 0 ? 1u : 0u, sc[2] += (unsigned)na;
+            sc[11] += (nd > 0 && na + nd > 64 - nd) ? 1u : 0u; // (approximate: a wave with dead lanes before the refill)
+            sc[12] += (unsigned)(na - (64 - nd));
+        }
+#endif
         // ---- scan (waves without a live lane skip it) ---------------------------------------------------------------------
         float t = 0.0f;
         int rec = -1;
@@ -645,6 +662,15 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
             V3 nd = d, mul = sf.color;
             float ntime = time;
             bool go = alive;
+#ifdef RT_COUNT_SHADE
+            {
+                const int n0 = __popcll(__ballot(alive & (cls == 0))), n1 = __popcll(__ballot(alive & (cls == 1))), n2 = __popcll(__ballot(alive & (cls == 2)));
+                sc[3] += n0 > 0 ? 1u : 0u, sc[4] += (unsigned)n0;
+                sc[5] += (n1 + n2) > 0 ? 1u : 0u, sc[6] += (unsigned)(n1 + n2);
+                sc[7] += n1 > 0 ? 1u : 0u, sc[8] += (unsigned)n1;
+                sc[9] += n2 > 0 ? 1u : 0u, sc[10] += (unsigned)n2;
+            }
+#endif
 #ifdef RT_MEASURE_SHADE_TWICE // development: the scatter once more on another stream, its result kept at zero weight
             {
                 Rng rng2{rng.x ^ 0x5bd1e995u};
@@ -671,6 +697,10 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         }
     }
 
+#ifdef RT_COUNT_SHADE
+    if (lane == 0)
+        for (int k = 0; k < 13; ++k) atomicAdd(&g_shade_counts[k], (unsigned long long)sc[k]);
+#endif
     if (!CHAIN) flush(A.atomic_out != 0); // CHAIN: every tile went out when the block moved on, the last one included (its pool
                                          // was empty, nothing was left to take: flushed below)
     if (CHAIN) flush(true);
@@ -1528,6 +1558,19 @@ extern "C" int rt_debug_walk_counts(unsigned long long *out4, int reset)
     RT_HIP(hipDeviceSynchronize());
     if (out4) RT_HIP(hipMemcpy(out4, p, 32, hipMemcpyDeviceToHost));
     if (reset) RT_HIP(hipMemset(p, 0, 32));
+    return RT_OK;
+}
+#endif
+
+#ifdef RT_COUNT_SHADE
+// development builds only (tools/shade_counts.py): the block kernel's shading census since the last reset
+extern "C" int rt_debug_shade_counts(unsigned long long *out16, int reset)
+{
+    void *p = nullptr;
+    RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_shade_counts)));
+    RT_HIP(hipDeviceSynchronize());
+    if (out16) RT_HIP(hipMemcpy(out16, p, 128, hipMemcpyDeviceToHost));
+    if (reset) RT_HIP(hipMemset(p, 0, 128));
     return RT_OK;
 }
 #endif
