@@ -120,7 +120,7 @@ def traffic_from_profile(cfg):
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_launch")
+        return json.load(f)
 
 
 def free_port():
@@ -261,7 +261,9 @@ def main(argv=None):
         if cfg["bound"] == "hbm":
             per = cfg.get("bytes_per_path") or counts.get("bytes_per_path")
             achieved = paths_per_launch * per / (k_ms * 1e-3) / 1e9 if per else None
-            peak, unit, note = HBM_PEAK_GBS, "GB/s", "algorithmic bytes: tree nodes visited x 32 B + leaves tested x 32 B per path"
+            peak, unit, note = HBM_PEAK_GBS, "GB/s", ("algorithmic bytes: tree nodes visited x 32 B + leaves tested x 32 B per path; "
+                                                "most are served by the L1s / L2 (l2_hit), so achieved may exceed the HBM peak: "
+                                                "traffic = what reached the memory side of the L2 (profiles/c5_traffic.json)")
         else:
             per = cfg.get("flop_per_path") or counts.get("flop_per_path")
             achieved = paths_per_launch * per / (k_ms * 1e-3) / 1e12 if per else None
@@ -279,7 +281,8 @@ def main(argv=None):
             "config": {"workload": f"{cfg['scene']} {nx}x{ny} {spp}spp depth {DEPTH} ({cfg['name']})", "partition": partition},
             "roofline": {"bound": cfg["bound"], "achieved": None if achieved is None else round(achieved, 4), "peak": peak,
                          "unit": unit, "frac": None if achieved is None else round(achieved / peak, 5),
-                         "traffic": traffic_from_profile(a.config), "kernel": kernel_name(), "kernel_ms": round(k_ms, 3),
+                         "traffic": (traffic_from_profile(a.config) or {}).get("hbm_bytes_per_launch"),
+                         "l2_hit": (traffic_from_profile(a.config) or {}).get("l2_hit"), "kernel": kernel_name(), "kernel_ms": round(k_ms, 3),
                          "per_path": per, "note": note},
         }
         if world == 1 and not a.no_cpu and not hook:
