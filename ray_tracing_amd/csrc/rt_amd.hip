@@ -768,10 +768,14 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 #define RT_LANES_WAVES_PER_EU 6
 #endif
 #ifdef RT_COUNT_WALK // development (tools/work_counts.py): what the walks of a launch touch -- the algorithmic bytes of the roofline
-__device__ unsigned long long g_walk_counts[4]; // node steps (one 32-byte node each), leaf tests (one 32-byte leaf each), rays, paths
+// [0] node steps (one 32-byte node each), [1] leaf tests (one 32-byte leaf each), [2] rays, [3] paths: per lane;
+// [4] node steps, [5] leaf phases, [6] shade phases a WAVE ran (whatever the number of lanes on), [7] lanes shaded
+__device__ unsigned long long g_walk_counts[8];
 #define RT_COUNT(k, cond) n_count[k] += (cond) ? 1u : 0u
+#define RT_COUNT_WAVE(k, any) do { const bool any_ = (any); n_count[k] += (lane == 0 && any_) ? 1u : 0u; } while (0)
 #else
 #define RT_COUNT(k, cond)
+#define RT_COUNT_WAVE(k, any)
 #endif
 template <bool TEX, bool BOX, int STEPS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
@@ -813,7 +817,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     rtf::Walk w;
     rtf::walk_start(w, r, RT_FLT_MAX, false);
 #ifdef RT_COUNT_WALK
-    unsigned n_count[4] = {0u, 0u, 0u, 0u};
+    unsigned n_count[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #endif
 
     for (;;) {
@@ -822,6 +826,8 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
         const int n_waiting = __popcll(__ballot(waiting));
         const bool walking_any = __any(w.cur != RT_BVH_NONE);
         if (n_waiting >= A.shade_batch || !walking_any) {
+            RT_COUNT_WAVE(6, n_waiting > 0);
+            RT_COUNT(7, waiting);
             if (waiting) {
                 const bool hit_any = w.best_prim >= 0;
                 rtf::Surface sf;
@@ -897,18 +903,20 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
             RT_COUNT(0, w.cur >= 0);
+            RT_COUNT_WAVE(4, __any(w.cur >= 0));
             if (w.cur >= 0) rtf::walk_node(S, w, 0.001f, stack);
         }
         const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
         if (__popcll(__ballot(at_leaf)) >= A.leaf_batch || !__any(w.cur >= 0)) {
             RT_COUNT(1, at_leaf);
+            RT_COUNT_WAVE(5, __any(at_leaf));
             if (at_leaf) rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
         }
     }
 
     flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
 #ifdef RT_COUNT_WALK
-    for (int k = 0; k < 4; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
 #endif
 }
 
@@ -1551,13 +1559,13 @@ extern "C" int rt_scene_set_option(rt_scene *s, int option, int value)
 
 #ifdef RT_COUNT_WALK
 // development builds only (tools/work_counts.py): node steps, leaf tests, rays and paths of the per-lane kernels since the last reset
-extern "C" int rt_debug_walk_counts(unsigned long long *out4, int reset)
+extern "C" int rt_debug_walk_counts(unsigned long long *out8, int reset)
 {
     void *p = nullptr;
     RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_walk_counts)));
     RT_HIP(hipDeviceSynchronize());
-    if (out4) RT_HIP(hipMemcpy(out4, p, 32, hipMemcpyDeviceToHost));
-    if (reset) RT_HIP(hipMemset(p, 0, 32));
+    if (out8) RT_HIP(hipMemcpy(out8, p, 64, hipMemcpyDeviceToHost));
+    if (reset) RT_HIP(hipMemset(p, 0, 64));
     return RT_OK;
 }
 #endif

@@ -315,6 +315,25 @@ def _gpu_rgb(sc, n, spp, seed):
     return gpu_render(sc, n, n, 0, spp, seed=seed)[..., 1:][..., ::-1] / spp
 
 
+def test_pixel_noise_falls_as_one_over_spp_up_to_65536():
+    """The per-path random stream is keyed by 32 bits (include/rt_rng.h): keys are unique within a pixel, but a 65 536-spp
+    render of this image draws 2.7e8 keys, so paths of DIFFERENT pixels share streams.  That must not show as a noise floor:
+    the mean squared difference of two renders over disjoint sample ranges (same seed), times spp, must stay what it is at
+    a few hundred samples.  (Caustic pixels make that product noisy, about +-25 % from size to size; a floor at the level of
+    N samples would multiply it by 65536 / N.)"""
+    n = 64
+    sc = Scene(HostScene("cornell_box", 1.0), 0)
+    v = {}
+    for spp in (256, 1024, 4096, 65536):
+        a = gpu_render(sc, n, n, 0, spp, seed=77)[..., 1:] / spp
+        b = gpu_render(sc, n, n, spp, 2 * spp, seed=77)[..., 1:] / spp
+        v[spp] = float(((a - b) ** 2).mean()) * spp
+    sc.close()
+    print({k: f"{x:.3f}" for k, x in v.items()})
+    low = np.mean([v[256], v[1024], v[4096]])
+    assert 0.4 * low <= v[65536] <= 1.6 * low, v
+
+
 def test_whole_image_statistics_equal_the_reference_at_1024_spp():
     """north_star check 2, pixel-level form.  If the GPU estimator and the reference's are the same random
     variable per pixel, the reference's 1024-spp image must sit exactly as far from the truth as a GPU 1024-spp
