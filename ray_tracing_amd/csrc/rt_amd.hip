@@ -1351,8 +1351,18 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
             if (s->opt_leaf_batch <= 0) A.leaf_batch = 4;
         }
         if (s->opt_node_steps == 2 || s->opt_node_steps == 4) steps = s->opt_node_steps; // RT_OPT_NODE_STEPS
+        // A chained grid must be what the chip holds at once: a block that has to wait for a place starts when the others are
+        // done, and does what is left alone.  How many blocks a CU holds depends on the LDS the tree's depth asks for (six at
+        // 23 levels, five at 28), so the runtime is asked.
 #define RT_LAUNCH_LANES(TEX, BOX, STEPS) \
-    hipLaunchKernelGGL((render_fastlanes_kernel<TEX, BOX, STEPS>), g, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter)
+    do { \
+        dim3 gs = g; \
+        int fit = 0; \
+        if (A.chain && s->opt_chain_blocks_per_cu <= 0 && \
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, render_fastlanes_kernel<TEX, BOX, STEPS>, 64 * WAVES_PER_BLOCK, lds) == hipSuccess && fit > 0) \
+            gs.x = (unsigned)std::min<int64_t>(blocks, (int64_t)s->n_cus * std::min(fit, (int)per_cu)); \
+        hipLaunchKernelGGL((render_fastlanes_kernel<TEX, BOX, STEPS>), gs, b, lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter); \
+    } while (0)
 #define RT_LAUNCH_LANES_STEPS(TEX, BOX) \
     do { if (steps == 4) RT_LAUNCH_LANES(TEX, BOX, 4); else RT_LAUNCH_LANES(TEX, BOX, 2); } while (0)
         if (s->fast_textured && s->lanes_boxes) RT_LAUNCH_LANES_STEPS(true, true);
