@@ -285,6 +285,12 @@ def main(argv=None):
                          "l2_hit": (traffic_from_profile(a.config) or {}).get("l2_hit"), "kernel": kernel_name(), "kernel_ms": round(k_ms, 3),
                          "per_path": per, "note": note},
         }
+        tr = traffic_from_profile(a.config) or {}
+        if tr.get("lane_steps_per_path") and tr.get("gather_limit_lane_steps_per_s"):
+            # config 5: the per-lane walk against the measured throughput of dependent 32-byte gathers (tools/ubench/gather_chain.hip)
+            rate = paths_per_launch * tr["lane_steps_per_path"] / (k_ms * 1e-3)
+            out["roofline"]["gather"] = {"achieved": round(rate, 1), "limit": tr["gather_limit_lane_steps_per_s"], "unit": "lane-steps/s (32 B each)",
+                                         "frac": round(rate / tr["gather_limit_lane_steps_per_s"], 4)}
         if world == 1 and not a.no_cpu and not hook:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
