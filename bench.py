@@ -50,6 +50,11 @@ CONFIGS = {
                name="BASELINE.json configs[2]", cpu_scene_flag=None),
     "c5": dict(scene="sphere_field_1m", nx=1920, ny=1080, spp=1024, bound="hbm", bytes_per_path=None,
                name="BASELINE.json configs[4]", cpu_scene_flag=None),
+    # (quoted on 8 GPUs; on fewer it is the same image, 6 s per step on one.  No FLOP count: at 16:9 the camera sees past
+    # the room's sides, a third of the paths end on their first ray, so the square image's 1.4 kFLOP per path does not hold
+    # and a per-path rate is not comparable with config 2's)
+    "c4": dict(scene="cornell_box", nx=3840, ny=2160, spp=16384, bound="valu_fp32", flop_per_path=None, no_counts=True,
+               name="BASELINE.json configs[3]", cpu_scene_flag=None),
 }
 
 
@@ -257,7 +262,7 @@ def main(argv=None):
         paths = nx * ny * spp
         value = paths / sec_per_step / 1e6
         paths_per_launch = nx * ny * (s1 - s0)
-        counts = load_work_counts().get(cfg["scene"], {})
+        counts = {} if cfg.get("no_counts") else load_work_counts().get(cfg["scene"], {})
         if cfg["bound"] == "hbm":
             per = cfg.get("bytes_per_path") or counts.get("bytes_per_path")
             achieved = paths_per_launch * per / (k_ms * 1e-3) / 1e9 if per else None

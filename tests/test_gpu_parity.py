@@ -315,6 +315,23 @@ def _gpu_rgb(sc, n, spp, seed):
     return gpu_render(sc, n, n, 0, spp, seed=seed)[..., 1:][..., ::-1] / spp
 
 
+def test_cornell_4k_rank_share_of_baseline_config_4():
+    """BASELINE config 4 at its full image size: 3840 x 2160, the last four samples of the 16 384 (what the tail of rank 7's
+    range looks like).  Every pixel gets its four samples, nothing is NaN or negative, the image mean is the small render's
+    (aspect ratio and camera equal), and the same range rendered in two halves adds up to it."""
+    nx, ny, s0, s1 = 3840, 2160, 16380, 16384
+    sc = Scene(HostScene("cornell_box", nx / ny), 0)
+    full = gpu_render(sc, nx, ny, s0, s1, seed=0)
+    assert sc.info(_capi.RT_INFO_LAST_RENDER_PATH) == _capi.RT_PATH_FAST
+    assert np.all(full[..., 0] == s1 - s0) and np.isfinite(full).all() and (full[..., 1:] >= 0).all()
+    halves = gpu_render(sc, nx, ny, s0, s0 + 2, seed=0) + gpu_render(sc, nx, ny, s0 + 2, s1, seed=0)
+    assert np.allclose(full, halves, rtol=1e-4, atol=1e-4)
+    small = gpu_render(sc, 384, 216, 0, 256, seed=3)
+    sc.close()
+    m_full, m_small = full[..., 1:].mean(axis=(0, 1)) / (s1 - s0), small[..., 1:].mean(axis=(0, 1)) / 256
+    assert np.allclose(m_full, m_small, rtol=0.03), (m_full, m_small)
+
+
 def test_pixel_noise_falls_as_one_over_spp_up_to_65536():
     """The per-path random stream is keyed by 32 bits (include/rt_rng.h): keys are unique within a pixel, but a 65 536-spp
     render of this image draws 2.7e8 keys, so paths of DIFFERENT pixels share streams.  That must not show as a noise floor:
