@@ -28,6 +28,26 @@ template <int KIND> __global__ __launch_bounds__(256) void k(float *out, int ite
             } else if (KIND == 4) {
                 asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 5\n v_readlane_b32 s22, %2, 7\n v_readlane_b32 s23, %3, 9"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"s20", "s21", "s22", "s23");
+            } else if (KIND == 6) {
+                asm volatile("v_cmp_gt_u64 vcc, %0, %1\n v_cmp_gt_u64 vcc, %1, %0\n v_cmp_gt_u64 vcc, %0, %1\n v_cmp_gt_u64 vcc, %1, %0"
+                             : "+v"(*(double *)&a0), "+v"(*(double *)&a2)::"vcc");
+            } else if (KIND == 7) {
+                asm volatile("v_mov_b64 %0, %1\n v_mov_b64 %1, %2\n v_mov_b64 %2, %3\n v_mov_b64 %3, %0"
+                             : "+v"(*(double *)&a0), "+v"(*(double *)&a2), "+v"(*(double *)&a4), "+v"(*(double *)&a6));
+            } else if (KIND == 8) {
+                asm volatile("v_cmp_le_f32 vcc, %0, %1\n v_cmp_le_f32 vcc, %1, %2\n v_cmp_le_f32 vcc, %2, %3\n v_cmp_le_f32 vcc, %3, %0"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"vcc");
+            } else if (KIND == 9) {
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %2, %3, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %3, %0, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %0, %1, %3 op_sel_hi:[1,0,0]"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            } else if (KIND == 10) {
+                asm volatile("v_min3_f32 %0, %1, %2, %0\n v_max3_f32 %1, %2, %3, %1\n v_med3_f32 %2, %3, %0, %2\n v_min3_f32 %3, %0, %1, %3"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            } else if (KIND == 11) {
+                asm volatile("v_sqrt_f32 %0, %0\n v_rsq_f32 %1, %1\n v_sin_f32 %2, %2\n v_cos_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            } else if (KIND == 12) {
+                asm volatile("v_cvt_f32_u32 %0, %1\n v_cvt_f32_u32 %2, %3\n v_xor_b32 %1, %1, %3\n v_lshrrev_b32 %3, 15, %3"
+                             : "+v"(a0), "+v"(u0), "+v"(a1), "+v"(u1));
             } else if (KIND == 5) {
                 asm volatile("v_pk_fma_f32 %0, %0, %0, %1\n v_pk_fma_f32 %1, %1, %1, %0" : "+v"(*(double *)&a0), "+v"(*(double *)&a2));
             }
@@ -69,5 +89,12 @@ int main()
     for (int w : {1, 4}) run<2>("v_rcp_f32", 4, w);
     for (int w : {1, 4}) run<3>("cmp+cndmask", 4, w);
     for (int w : {1, 4}) run<4>("v_readlane", 4, w);
+    for (int w : {4, 8}) run<6>("v_cmp_gt_u64", 4, w);
+    for (int w : {4, 8}) run<7>("v_mov_b64", 4, w);
+    for (int w : {4, 8}) run<8>("v_cmp_le_f32", 4, w);
+    for (int w : {4, 8}) run<9>("v_fma_mix_f32", 4, w);
+    for (int w : {4, 8}) run<10>("min3/max3/med3", 4, w);
+    for (int w : {4, 8}) run<11>("sqrt/rsq/sin/cos", 4, w);
+    for (int w : {4, 8}) run<12>("cvt/xor/shift", 4, w);
     return 0;
 }
