@@ -12,9 +12,14 @@
  * path (jitter u, jitter v, lens disk, shutter time, then per bounce: media met
  * during traversal, then the material / pdf draws).  The CPU oracle can run on
  * this same stream, which makes per-pixel comparison possible.
- * One deliberate difference: when the camera's lens radius is exactly zero the
- * lens-disk rejection loop is not run at all (the reference draws it and then
- * multiplies the point by zero, src/camera.h:56), so no draws are spent on it.
+ * Two deliberate differences, both where the reference draws numbers and then
+ * multiplies them by an exact zero: when the camera's lens radius is exactly
+ * zero the lens-disk rejection loop is not run at all (src/camera.h:56), and
+ * when a metal's fuzz is exactly zero neither is the unit-sphere rejection loop
+ * of its scatter (src/material.h:71: reflected + fuzz*random_in_unit_sphere()).
+ * No draws are spent on either; the image has the same distribution (on the
+ * GPU the second loop, run by whole waves until their slowest lane accepts,
+ * was 9 % of the Cornell box's render time for a vector that was never used).
  *
  * This header is plain C and is included by host code, the oracle and the HIP
  * kernels alike; it is part of the ABI (changing it changes every image).

@@ -555,7 +555,8 @@ V3 color(const rt_scene_desc *sc, const Ray &r, int max_depth, int depth, Rng &r
     }
     case RT_MAT_METAL: { // src/material.h:65-78
         V3 reflected = reflect(unit(r.d), h.n);
-        V3 fuzz = m.p0 * random_in_unit_sphere(rng);
+        // (per-path stream: no draws at fuzz 0, include/rt_rng.h; the reference's stream draws them as the reference does)
+        V3 fuzz = (rng.mode == ORC_RNG_COUNTER && m.p0 == 0.0f) ? v3(0, 0, 0) : m.p0 * random_in_unit_sphere(rng);
         Ray spec{h.p, reflected + fuzz, r.time};
         V3 albedo = tex_value(sc, m.texture, h.u, h.v, h.p);
         return albedo * color(sc, spec, max_depth, depth + 1, rng);

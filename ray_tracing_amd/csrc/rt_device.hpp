@@ -861,9 +861,10 @@ RT_DEV bool shade(const DevScene &S, bool hit_any, const Hit &h, Ray &r, V3 &T, 
         }
         return true;
     }
-    if (m.kind == RT_MAT_METAL) { // src/material.h:65-78; the sphere sample is drawn even at fuzz 0
+    if (m.kind == RT_MAT_METAL) { // src/material.h:65-78; at fuzz 0 the sphere sample is not drawn (include/rt_rng.h)
         V3 reflected = reflect(unit(r.d), h.n);
-        V3 fuzz = m.p0 * random_in_unit_sphere(rng);
+        V3 fuzz = v3(0, 0, 0);
+        if (m.p0 != 0.0f) fuzz = m.p0 * random_in_unit_sphere(rng);
         T = T * tex_value(S, m.texture, h.u, h.v, h.p);
         r = Ray{h.p, reflected + fuzz, r.time};
         return true;

@@ -743,7 +743,8 @@ RTF_DEV void scatter_specular(const Surface &h, V3 rd, Rng &rng, V3 &nd, V3 &mul
     if (h.mat_kind == RT_MAT_METAL) {
         const V3 ud = funit(rd);
         const float k = 2.0f * fdot(ud, h.n);
-        const V3 fz = rnd_unit_sphere(rng);
+        V3 fz = v3(0, 0, 0); // at fuzz 0 the sphere sample is not drawn (include/rt_rng.h)
+        if (h.p0 != 0.0f) fz = rnd_unit_sphere(rng);
         nd = v3(fmaf(h.p0, fz.x, ud.x - k * h.n.x), fmaf(h.p0, fz.y, ud.y - k * h.n.y), fmaf(h.p0, fz.z, ud.z - k * h.n.z));
     } else if (h.mat_kind == RT_MAT_DIELECTRIC) {
         const float inv_len = rsq(fdot(rd, rd));
