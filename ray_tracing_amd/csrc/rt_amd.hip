@@ -968,7 +968,7 @@ struct rt_scene {
     bool lanes_boxes = false;   // its tree holds box leaves or media bounded by boxes (rt_box.h)
     int bvh_levels = 1;         // inner levels of that tree (rt_bvh_build)
     const char *fast_why = "";
-    rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0};
+    rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0, 0u, 0.0f};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids and 64 x 6 face ids (inside blob)
     int32_t *d_rec_user = nullptr;
     unsigned *d_task_counters = nullptr; // inside blob: 64 task counters of the chained kernels, used in turn (each zeroed
@@ -1234,7 +1234,7 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
     }
-    s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights, {tab.run[0], tab.run[1], tab.run[2], tab.run[3]}, tab.n_runs, tab.n_spheres, 0u};
+    s->layout = rtf::Layout{tab.n_stream, tab.materials_base, tab.lights_base, tab.n_lights, {tab.run[0], tab.run[1], tab.run[2], tab.run[3]}, tab.n_runs, tab.n_spheres, 0u, tab.n_lights > 0 ? 1.0f / (float)tab.n_lights : 0.0f};
     for (int k = 0; k < tab.n_lights && k < 32; ++k)
         if ((tab.rec[tab.lights_base + k][7] & 15u) == RT_REC_LIGHT_RECT) s->layout.rect_lights |= 1u << k;
     s->fast_flat = fast_ok && tab.flat != 0 && tab.n_runs > 0; // the run scan; else the generic one (it also walks flat streams)

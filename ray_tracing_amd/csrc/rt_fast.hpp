@@ -71,6 +71,7 @@ struct Layout { // wave-uniform description of the table
     uint32_t run[RT_REC_MAX_RUNS]; // rt_records.h: the runs of a flat stream
     int32_t n_runs, n_spheres;
     uint32_t rect_lights; // bit k: member k of the important list is a rect (the first 32 members)
+    float inv_n_lights;   // 1 / n_lights (hitable_list::pdf_value's weight, src/hitable_list.h:69), from the host
 };
 
 // Arithmetic that decides WHICH primitive is hit (north_star check 1: ids equal to the reference's hitable::hit).
@@ -130,7 +131,8 @@ RTF_DEV SRec load_rec(const uint32_t *__restrict__ recs, int i)
 RTF_DEV float sf(const SRec &r, int k) { return __uint_as_float(r.d[k]); }
 
 // translate::hit / rotate_y::hit on the way down (src/transforms.h:17, 107-110), operations from records
-RTF_DEV void apply_chain(const uint32_t *__restrict__ recs, uint32_t chain_bits, const Ray &wr, LocalRay &l)
+// (translate and rotate_y leave a direction's y alone, so 1/d.y is the world ray's: one reciprocal and its refinement less)
+RTF_DEV void apply_chain(const uint32_t *__restrict__ recs, uint32_t chain_bits, const Ray &wr, float world_inv_y, LocalRay &l)
 {
     V3 o = wr.o, d = wr.d;
     const int first = chain_bits & 63, count = chain_bits >> 6;
@@ -145,7 +147,8 @@ RTF_DEV void apply_chain(const uint32_t *__restrict__ recs, uint32_t chain_bits,
             o.x = ox, o.z = oz, d.x = dx, d.z = dz;
         }
     }
-    set_local(l, o, d);
+    l.o = o, l.d = d;
+    l.inv = v3(refined_rcp(d.x), world_inv_y, refined_rcp(d.z));
 }
 
 // ---------------------------------------------------------------------------
@@ -351,10 +354,11 @@ RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs,
     Best best = best_start(t_max);
     LocalRay l;
     set_local(l, wr.o, wr.d);
+    const float world_inv_y = l.inv.y;
     int index = 0;
     for (int r = 0; r < Y.n_runs; ++r) {
         const uint32_t w = Y.run[r];
-        if ((w >> 15) & RT_KW_CHAIN_MASK) apply_chain(recs, (w >> 15) & RT_KW_CHAIN_MASK, wr, l);
+        if ((w >> 15) & RT_KW_CHAIN_MASK) apply_chain(recs, (w >> 15) & RT_KW_CHAIN_MASK, wr, world_inv_y, l);
         rect_run(lrecs, index, (int)((w >> 10) & 31u), t_min, l.o.z, l.d.z, l.inv.z, l.o.x, l.d.x, l.o.y, l.d.y, best);
         rect_run(lrecs, index, (int)((w >> 5) & 31u), t_min, l.o.y, l.d.y, l.inv.y, l.o.x, l.d.x, l.o.z, l.d.z, best);
         rect_run(lrecs, index, (int)(w & 31u), t_min, l.o.x, l.d.x, l.inv.x, l.o.y, l.d.y, l.o.z, l.d.z, best);
@@ -429,7 +433,7 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, cons
             const uint32_t chain = (kw >> RT_KW_CHAIN_SHIFT) & RT_KW_CHAIN_MASK;
             if (chain != cur_chain) {
                 if (chain == 0) l = w;
-                else apply_chain(recs, chain, wr, l);
+                else apply_chain(recs, chain, wr, w.inv.y, l);
                 cur_chain = chain;
             }
         }
@@ -573,17 +577,18 @@ struct Onb {
 RTF_DEV bool within(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi) == x; } // lo <= x <= hi, false for NaN
 RTF_DEV float lights_pdf_value(const uint32_t *__restrict__ recs, const Layout &Y, V3 o, V3 v)
 {
-    const float weight = rcp((float)Y.n_lights);
+    const float weight = Y.inv_n_lights;
     float sum = 0.0f;
     for (int k = 0; k < Y.n_lights; ++k) {
         const SRec c = load_rec(recs, Y.lights_base + k);
         const uint32_t kind = c.d[7] & 15u;
         float pdf = 0.0f;
         if (kind == RT_REC_LIGHT_RECT) { // xz_rect::pdf_value, src/plane.h:76-91
-            const float t = (sf(c, 4) - o.y) * rcp(v.y);
+            const float iy = rcp(v.y);
+            const float t = (sf(c, 4) - o.y) * iy;
             const float x = fmaf(t, v.x, o.x), z = fmaf(t, v.z, o.z);
             const bool in = (t >= 0.0001f) & within(x, sf(c, 0), sf(c, 1)) & within(z, sf(c, 2), sf(c, 3));
-            pdf = in ? t * t * rcp(fabsf(v.y) * sf(c, 5)) : 0.0f;
+            pdf = in ? t * t * (fabsf(iy) * sf(c, 6)) : 0.0f; // t^2 / (|v.y| area): the record carries 1 / area beside the area
         } else if (kind == RT_REC_LIGHT_SPHERE) { // sphere::pdf_value, src/sphere.h:68-83
             const V3 oc = v3(o.x - sf(c, 0), o.y - sf(c, 1), o.z - sf(c, 2));
             const float radius = sf(c, 3);

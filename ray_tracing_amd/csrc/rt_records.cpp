@@ -62,6 +62,7 @@ int emit_lights(const rt_scene_desc *d, rt_record_table *out, int at)
         for (int k = 0; k < 5; ++k) r[k] = fbits(p.f[k]);
         if (p.kind == RT_PRIM_XZ_RECT) {
             r[5] = fbits((p.f[1] - p.f[0]) * (p.f[3] - p.f[2])); // area, src/plane.h:82
+            r[6] = fbits(1.0f / ((p.f[1] - p.f[0]) * (p.f[3] - p.f[2])));
             r[7] = RT_REC_LIGHT_RECT;
         } else {
             r[7] = RT_REC_LIGHT_SPHERE;
