@@ -158,7 +158,9 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, int *stack)
     const float tf1 = fminf(fmin3(fmaxf(x10, x11), fmaxf(y10, y11), fmaxf(z10, z11)), w.best_t);
     const int ref0 = (int)a.w, ref1 = (int)b.w;
     const bool h0 = tf0 >= tn0, h1 = (tf1 >= tn1) & (ref1 != RT_BVH_NONE);
-    const bool first0 = tn0 <= tn1;
+// (a ray that starts inside both boxes enters both at t_min: the box it leaves first -- the tighter one -- goes first;
+    // random spheres +2 %, 1M spheres +1 %)
+    const bool first0 = (tn0 < tn1) | ((tn0 == tn1) & (tf0 <= tf1));
     const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
     const bool hn = first0 ? h0 : h1, hf = first0 ? h1 : h0;
     if (hn & hf) {
