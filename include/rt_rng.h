@@ -6,7 +6,8 @@
  * which every worker thread shares without a lock.  On the GPU each path
  * (pixel, sample) owns a stream: draw number n of a path is a pure function of
  * (seed, pixel, sample, n), so an image does not depend on how paths are
- * scheduled over lanes, waves or GPUs.
+ * scheduled over lanes, waves or GPUs.  A path's identity has 64 bits: a 32-bit
+ * key of (sample, seed) and the 32-bit pixel index (rt_mix32_w below).
  *
  * The kernels consume draws in the order the reference's code does along one
  * path (jitter u, jitter v, lens disk, shutter time, then per bounce: media met
@@ -46,19 +47,35 @@ RT_RNG_FN uint32_t rt_mix32(uint32_t x)
     return x;
 }
 
-/* pixel = row * nx + column with row 0 at the top of the image (the order of
- * the output buffer); sample = sample_index * sub_samples + sub_sample. */
-RT_RNG_FN uint32_t rt_path_key(uint32_t seed, uint32_t pixel, uint32_t sample)
+/* The finaliser over two words: the second one is XORed into the first before the mixing.  For a fixed `w` it is a
+ * bijection of x, and for a fixed x a bijection of w: two streams that differ in `w` never produce the same word at the
+ * same position, and because every input bit reaches every output bit through both multiplies, streams whose `w`
+ * differ in a single low bit (neighbouring pixels) are uncorrelated (tests/test_rng.py measures it).
+ * (Folding `w` in BETWEEN the two multiplies -- one round of mixing for it -- was tried first and is not enough: a
+ * one-bit difference then shifts the product by a constant, and neighbouring pixels' draws came out with a
+ * correlation of -0.49.)
+ * `w` is the path's pixel index, so a path's identity is the 64-bit pair (key, pixel) although the state a lane carries
+ * from draw to draw is still one 32-bit counter (the pixel is recomputed from the tile and the lane's place in it
+ * wherever draws are made: no register, no word in the kernels' path exchange).  The streams of a pixel are windows
+ * of that pixel's own 2^32-long sequence mix(c ^ pixel).
+ * Round 2's stream was keyed by 32 bits in all and every stream was a window of ONE sequence: at the 2^37 paths of a
+ * 3840 x 2160 x 16384 spp image every key value was shared by about 32 paths in different pixels.  Now paths of
+ * different pixels never share a stream, and within a pixel the keys of samples 0 .. 2^32-1 are all different
+ * (rt_path_key is a bijection of `sample` for a fixed seed). */
+RT_RNG_FN uint32_t rt_mix32_w(uint32_t x, uint32_t w) { return rt_mix32(x ^ w); }
+
+/* sample = sample_index * sub_samples + sub_sample */
+RT_RNG_FN uint32_t rt_path_key(uint32_t seed, uint32_t sample)
 {
-    uint32_t k = rt_mix32(pixel * 0x9E3779B9U + 0x85EBCA6BU);
-    k = rt_mix32(k ^ (sample * 0xC2B2AE35U + seed * 0x27D4EB2FU + 1U));
-    return k;
+    return rt_mix32(sample * 0xC2B2AE35U + seed * 0x27D4EB2FU + 1U);
 }
 
-/* n-th draw of a path, uniform in [0,1) with 24 random bits */
-RT_RNG_FN float rt_draw(uint32_t key, uint32_t n)
+/* n-th draw of the path (key, pixel), uniform in [0,1) with 24 random bits.
+ * pixel = row * nx + column with row 0 at the top of the image (the order of the output buffer); for the closest-hit
+ * entry points (rt_trace_rays) it is the index of the ray in the batch and the key is rt_path_key(seed, 0). */
+RT_RNG_FN float rt_draw(uint32_t key, uint32_t pixel, uint32_t n)
 {
-    uint32_t x = rt_mix32(key + n * 0x9E3779B9U);
+    uint32_t x = rt_mix32_w(key + n * 0x9E3779B9U, pixel);
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 

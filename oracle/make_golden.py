@@ -8,6 +8,9 @@ The fixtures are inputs and expected outputs (data), not source.
 
     python oracle/make_golden.py            # everything except the slow converged image
     python oracle/make_golden.py --scenes cornell_box --image   # + Cornell 256x256 at 1024/4096/8192 spp (about 25 minutes)
+    python oracle/make_golden.py --converged     # converged images WITH second moments of the scenes of BASELINE configs 1, 3, 5 and the
+        # smoke-box Cornell variant (CONVERGED below; 4 processes, about 12 minutes), each inside the period of minstd_rand0:
+        # the harness counts the draws exactly and this script refuses a fixture that used more than 80 % of the period
     python oracle/make_golden.py --scenes cornell_box --image96 --only-images   # Cornell 96x96 at 4096/8192 spp (3 minutes):
         # the converged image that stays INSIDE the period of the reference's minstd_rand0 (2^31-2 draws; a path takes
         # about 25, so 96*96*8192 paths draw 1.9e9), which a 256x256 render leaves after about 1300 spp
@@ -31,14 +34,50 @@ def run(*args):
     subprocess.run(cmd, check=True)
 
 
+# scene -> (nx, ny, spp): what `--converged` renders with the reference's own compute_one_sample_task / color().
+# spp is as large as the generator's period allows (draws per sample image measured by the harness: random_spheres 70k,
+# next_week_final 193k, cornell_box_volumes 89k, sphere_field_4k 67k), so the standard errors of the fixture are small.
+CONVERGED = {
+    "random_spheres": (96, 64, 16384),
+    "next_week_final": (64, 64, 8192),
+    "cornell_box_volumes": (64, 64, 16384),
+    "sphere_field_4k": (64, 64, 8192),
+}
+
+
+def converged():
+    import re
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = {}
+        for scene, (nx, ny, spp) in CONVERGED.items():
+            cmd = [HARNESS, "imagesq", scene, str(nx), str(ny), str(spp), "50", f"{tmp}/{scene}.npy"]
+            print("+", " ".join(cmd), flush=True)
+            procs[scene] = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        for scene, p in procs.items():
+            out = p.communicate()[0]
+            if p.returncode:
+                raise SystemExit(f"{scene}: harness failed")
+            draws, period = map(int, re.search(r"draws (\d+) period (\d+)", out).groups())
+            nx, ny, spp = CONVERGED[scene]
+            print(f"{scene}: {draws} draws = {draws / period:.3f} of the period", flush=True)
+            if draws > 0.8 * period:
+                raise SystemExit(f"{scene}: leaves the generator's period; lower spp")
+            a = np.load(f"{tmp}/{scene}.npy")
+            np.savez_compressed(os.path.join(GOLD, f"{scene}_{nx}x{ny}_{spp}spp_r50_moments.npz"), moments=a,
+                                draws=np.int64(draws), spp=np.int32(spp))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--converged", action="store_true", help="only the converged images with second moments (CONVERGED)")
     ap.add_argument("--image", action="store_true", help="also render the 4096-spp converged image")
     ap.add_argument("--image96", action="store_true", help="also render the within-period 96x96 converged images")
     ap.add_argument("--only-images", action="store_true", help="leave the .npz fixtures and kat.npz as they are")
     ap.add_argument("--scenes", default="cornell_box,cornell_box_volumes,random_spheres,next_week_final")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
+    if a.converged:
+        return converged()
     with tempfile.TemporaryDirectory() as tmp:
         for scene in a.scenes.split(","):
             out = {}

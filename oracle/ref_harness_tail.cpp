@@ -12,6 +12,8 @@
 // Modes (see oracle/make_golden.py for the exact invocations):
 //   samples <scene> nx ny ns nss depth out.npy   per-sample float buffers, -t 1 order
 //   image   <scene> nx ny ns depth out.npy       mean float RGB after ns samples, -t 1
+//   imagesq <scene> nx ny ns depth out.npy       per pixel mean and mean square of the samples (r,g,b,rr,gg,bb), -t 1;
+//                                                prints the exact number of RAN01() draws the run consumed
 //   hits    <scene> nx ny out.npy                primary-ray closest hits + primitive ids
 //   tree    <scene> out.txt                      depth-first dump of the final BVH
 //   kat     outdir                               per-function known-answer vectors
@@ -20,6 +22,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -145,6 +148,76 @@ static int mode_image(int argc, char **argv)
     float inv = 1.0f / ns;
     for (float &x : sum) x *= inv;
     write_f32(argv[7], sum, {(size_t)ny, (size_t)nx, 3});
+    return 0;
+}
+
+
+// ---- imagesq: image + second moments + an exact count of the draws ------------------
+// The reference's engine is libstdc++'s minstd_rand0 (src/main.cpp:62): x <- 16807 x mod (2^31 - 1), period
+// 2^31 - 2.  The number of draws between two states is a discrete logarithm in that group, small enough for
+// baby-step giant-step; summed over the sample tasks it says whether a fixture stayed inside the period
+// (beyond it the reference replays its numbers and the "samples" are no longer independent).
+struct draw_counter {
+    static constexpr uint64_t M = 2147483647ull, A = 16807ull;
+    std::map<uint32_t, uint32_t> baby; // A^j -> j, j < 2^16
+    uint64_t giant_inv;                // A^(-2^16)
+    static uint64_t powm(uint64_t b, uint64_t e) { uint64_t r = 1; b %= M; while (e) { if (e & 1) r = r * b % M; b = b * b % M; e >>= 1; } return r; }
+    draw_counter()
+    {
+        uint64_t x = 1;
+        for (uint32_t j = 0; j < 65536; ++j) { baby.emplace((uint32_t)x, j); x = x * A % M; }
+        giant_inv = powm(powm(A, 65536), M - 2);
+    }
+    static uint64_t state_now()
+    {
+        std::ostringstream os;
+        os << generator;
+        return std::stoull(os.str());
+    }
+    // draws between two states, modulo the period
+    uint64_t between(uint64_t s0, uint64_t s1) const
+    {
+        uint64_t y = s1 * powm(s0, M - 2) % M; // = A^n
+        for (uint64_t i = 0; i < 32768; ++i) {
+            auto it = baby.find((uint32_t)y);
+            if (it != baby.end()) return i * 65536 + it->second;
+            y = y * giant_inv % M;
+        }
+        return ~0ull;
+    }
+};
+
+static int mode_imagesq(int argc, char **argv)
+{
+    if (argc != 8) return 2;
+    int nx = atoi(argv[3]), ny = atoi(argv[4]), ns = atoi(argv[5]), depth = atoi(argv[6]);
+    scene_t s = build(argv[2], nx, ny);
+    draw_counter dc;
+    uint64_t draws = 0, st = draw_counter::state_now();
+    // sums in double: the fixture is a statistic of the reference's samples, not a restatement of its resolve loop
+    std::vector<double> sum((size_t)nx * ny * 6, 0.0);
+    std::vector<float> one((size_t)nx * ny * 4);
+    for (int i = 0; i < ns; ++i) {
+        compute_one_sample_task *t = new compute_one_sample_task();
+        t->image_width = nx, t->image_height = ny, t->sub_samples = 1, t->sample_id = i, t->max_depth = depth;
+        t->shared_buffer = one.data();
+        t->world = s.root, t->important_hitables = s.important, t->cam = s.cam;
+        t->run();
+        uint64_t now = draw_counter::state_now();
+        draws += dc.between(st, now);
+        st = now;
+        for (size_t p = 0; p < (size_t)nx * ny; ++p)
+            for (int c = 0; c < 3; ++c) {
+                double v = one[4 * p + 3 - c]; // r, g, b
+                sum[6 * p + c] += v;
+                sum[6 * p + 3 + c] += v * v;
+            }
+        if ((i & 63) == 63) fprintf(stderr, "%d/%d draws %llu\n", i + 1, ns, (unsigned long long)draws);
+    }
+    std::vector<float> out(sum.size());
+    for (size_t k = 0; k < sum.size(); ++k) out[k] = (float)(sum[k] / ns);
+    write_f32(argv[7], out, {(size_t)ny, (size_t)nx, 6});
+    printf("draws %llu period %llu\n", (unsigned long long)draws, (unsigned long long)(draw_counter::M - 1));
     return 0;
 }
 
@@ -544,11 +617,12 @@ static int mode_kat(int argc, char **argv)
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: ref_harness samples|image|hits|tree|kat ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness samples|image|imagesq|hits|tree|kat ...\n"); return 2; }
     std::string m = argv[1];
     int rc = 2;
     if (m == "samples") rc = harness::mode_samples(argc, argv);
     else if (m == "image") rc = harness::mode_image(argc, argv);
+    else if (m == "imagesq") rc = harness::mode_imagesq(argc, argv);
     else if (m == "hits") rc = harness::mode_hits(argc, argv);
     else if (m == "tree") rc = harness::mode_tree(argc, argv);
     else if (m == "kat") rc = harness::mode_kat(argc, argv);

@@ -97,11 +97,11 @@ struct Rng {
     std::default_random_engine *engine = nullptr;
     std::uniform_real_distribution<float> *dist = nullptr;
     // COUNTER: include/rt_rng.h
-    uint32_t key = 0, n = 0;
+    uint32_t key = 0, pixel = 0, n = 0;
     float next()
     {
         if (mode == ORC_RNG_MINSTD) return (*dist)(*engine);
-        return rt_draw(key, n++);
+        return rt_draw(key, pixel, n++);
     }
 };
 
@@ -622,8 +622,8 @@ inline void shade_pixel(const rt_scene_desc *sc, int nx, int ny, int i, int j, i
     for (int s = 0; s < nss; ++s) {
         if (rng.mode == ORC_RNG_COUNTER) {
             uint32_t pixel = (uint32_t)((ny - 1 - j) * nx + i);
-            rng.key = rt_path_key(seed, pixel, (uint32_t)(sample * nss + s));
-            rng.n = 0;
+            rng.key = rt_path_key(seed, (uint32_t)(sample * nss + s));
+            rng.pixel = pixel, rng.n = 0;
         }
         float u = float(i + rng.next()) / float(nx);
         float v = float(j + rng.next()) / float(ny);
@@ -654,6 +654,16 @@ void merge_counters()
 extern "C" {
 
 void orc_set_perlin_table(const float *table_256x3) { g_perlin_table = table_256x3; }
+
+// include/rt_rng.h as compiled: draws 0..n-1 of the path (seed, pixel, sample) -- tests/test_rng.py pins the header's
+// arithmetic against a numpy restatement and checks the properties the kernels rely on
+void orc_rng_draws(uint32_t seed, uint32_t pixel, uint32_t sample, int n, float *out)
+{
+    const uint32_t key = rt_path_key(seed, sample);
+    for (int k = 0; k < n; ++k) out[k] = rt_draw(key, pixel, (uint32_t)k);
+}
+uint32_t orc_rng_key(uint32_t seed, uint32_t sample) { return rt_path_key(seed, sample); }
+uint32_t orc_rng_mix_w(uint32_t x, uint32_t w) { return rt_mix32_w(x, w); }
 
 // Renders samples [sample_begin, sample_end).  out_sum: ny*nx*4 floats, per pixel
 // [A,B,G,R] summed over the samples in sample order (what src/main.cpp:720-726
@@ -757,7 +767,7 @@ void orc_trace_rays(const rt_scene_desc *sc, int n, const float *rays, float t_m
         const float *f = rays + 7 * k;
         Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
         Rng rng;
-        rng.mode = ORC_RNG_COUNTER, rng.key = rt_path_key(seed, (uint32_t)k, 0), rng.n = 0;
+        rng.mode = ORC_RNG_COUNTER, rng.key = rt_path_key(seed, 0), rng.pixel = (uint32_t)k, rng.n = 0;
         Rec h;
         rt_hit &o = out[k];
         memset(&o, 0, sizeof o);

@@ -135,7 +135,7 @@ __device__ __forceinline__ void render_exact(DevScene S, RenderArgs A, float *__
     bool alive = false;
     Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
     V3 T = v3(1, 1, 1);
-    Rng rng{0u};
+    Rng rng{0u, 0u};
     int depth = 0, pix = lane;
 
     for (;;) {
@@ -151,7 +151,7 @@ __device__ __forceinline__ void render_exact(DevScene S, RenderArgs A, float *__
                 const int sub = q - (q / A.sub_samples) * A.sub_samples;
                 const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3); // row 0 = image top
                 if (col < A.nx && row < A.ny) {
-                    rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
+                    rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), (uint32_t)(row * A.nx + col));
                     // compute_one_sample_task::run, src/main.cpp:230-233; j counts rows from the bottom
                     const int j = A.ny - 1 - row;
                     const float u = float(col + rng.next()) / float(A.nx);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, int n, const flo
     int k = alive ? i : 0;
     const float *f = rays + 7 * (size_t)k;
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
-    Rng rng{rt_path_key(seed, (uint32_t)k, 0u)};
+    Rng rng{rt_path_key(seed, 0u), (uint32_t)k};
     Hit h;
     static_assert(WAVES_PER_BLOCK * 64 == 256, "trace_kernel is launched with 256 threads");
     int *stack = LaneStacks<LANES>::get(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
     bool alive = false;
     Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
     V3 T = v3(1, 1, 1);
-    Rng rng{0u};
+    Rng rng{0u, 0u}; // (this kernel carries the pixel word: it has the register)
     int depth = 0, pix = lane;
 
     for (;;) {
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
                 const int sub = q - qs * A.sub_samples;
                 const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
                 if (col < A.nx && row < A.ny) {
-                    rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
+                    rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), (uint32_t)(row * A.nx + col));
                     const int j = A.ny - 1 - row;
                     const float u = (float(col) + rng.next()) * inv_nx;
                     const float v = (float(j) + rng.next()) * inv_ny;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
             Ray r2 = r;
             V3 T2 = T, L2;
             int depth2 = depth;
-            Rng rng2{rng.x ^ 0x5bd1e995u};
+            Rng rng2{rng.x ^ 0x5bd1e995u, rng.w};
             const bool g2 = rtf::shade<TEX>(S, recs, Y, rec >= 0, sf, r2, T2, depth2, A.max_depth, rng2, L2);
             keep = (g2 ? r2.d.x + T2.y : L2.z) * 1e-30f;
         }
@@ -431,9 +431,18 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     int tile_x, tile_y, s0, s1; // TW x 16 tiles
     unsigned total;
     int old_tile_x = 0, old_tile_y = 0; // CHAIN: where the paths of the previous task belong
+    // The pixel word of the random stream (include/rt_rng.h: row * nx + column) is not carried from bounce to bounce -- the
+    // kernel has no register for it at eight waves per SIMD and the exchange no word -- but set again wherever draws are
+    // made, from the tile's first pixel (wave-uniform) and the lane's place in the tile.
+    uint32_t pix_base = 0u, old_pix_base = 0u;
+    auto pixel_word = [&](int px, int was_old) {
+        const uint32_t u = (uint32_t)px; // (24-bit multiply-add: full rate; nx <= 65536)
+        return (CHAIN && was_old ? old_pix_base : pix_base) + (__umul24(u / (uint32_t)TW, (uint32_t)A.nx) + u % (uint32_t)TW);
+    };
     auto open_task = [&](int tk) {
         const int tile = tk / A.n_chunks, chunk = tk - tile * A.n_chunks;
         tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
+        pix_base = (uint32_t)(tile_y * 16) * (uint32_t)A.nx + (uint32_t)(tile_x * TW);
         s0 = chunk * A.chunk_samples;
         s1 = min(s0 + A.chunk_samples, A.n_samples);
         total = tk < A.n_tasks ? (unsigned)NT * (unsigned)((s1 - s0) * A.sub_samples) : 0u;
@@ -463,7 +472,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     bool alive = false;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), T = v3(1, 1, 1);
     float time = 0.0f;
-    Rng rng{0u};
+    Rng rng{0u, 0u};
     int depth = 0, pix = tid;
     int turn = 0;
     int old = 0; // CHAIN: 1 = this lane's path belongs to the previous task
@@ -489,7 +498,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                     const int sub = q - qs * A.sub_samples;
                     const int col = tile_x * TW + (pix % TW), row = tile_y * 16 + (pix / TW);
                     if (col < A.nx && row < A.ny) {
-                        rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
+                        rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), (uint32_t)(row * A.nx + col));
                         const int j = A.ny - 1 - row;
                         const float u = (float(col) + rng.next()) * inv_nx;
                         const float v = (float(j) + rng.next()) * inv_ny;
@@ -558,6 +567,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                 cls = 0;
                 if (mat_kind == RT_MAT_LAMBERTIAN) {
                     cls = 2;
+                    rng.w = pixel_word(pix, old);
                     to_light = rng.next() < 0.5f ? 1 : 0;
                     if (to_light) {
                         light = rtf::lights_index(Y, rng);
@@ -632,7 +642,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                 // the tile goes to the image, the paths still on their way become the previous task's, the next task opens
                 flush(true); // (every thread reads and clears the sums of its own pixel only: no barrier in between)
                 acc[tid] = 0.0f, acc[NT + tid] = 0.0f, acc[2 * NT + tid] = 0.0f;
-                old_tile_x = tile_x, old_tile_y = tile_y;
+                old_tile_x = tile_x, old_tile_y = tile_y, old_pix_base = pix_base;
                 old = alive ? 1 : 0;
                 if (tid == 0) {
                     task_now = (int)(atomicAdd(next_task, 1u) + gridDim.x);
@@ -662,6 +672,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
             V3 nd = d, mul = sf.color;
             float ntime = time;
             bool go = alive;
+            rng.w = pixel_word(pix, old); // the path this lane took over in the exchange
 #ifdef RT_COUNT_SHADE
             {
                 const int n0 = __popcll(__ballot(alive & (cls == 0))), n1 = __popcll(__ballot(alive & (cls == 1))), n2 = __popcll(__ballot(alive & (cls == 2)));
@@ -673,7 +684,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
 #endif
 #ifdef RT_MEASURE_SHADE_TWICE // development: the scatter once more on another stream, its result kept at zero weight
             {
-                Rng rng2{rng.x ^ 0x5bd1e995u};
+                Rng rng2{rng.x ^ 0x5bd1e995u, rng.w};
                 V3 nd2 = d, mul2 = sf.color;
                 bool go2 = alive;
                 if (alive & (cls == 0)) rtf::scatter_specular(sf, d, rng2, nd2, mul2, ntime);
@@ -812,8 +823,13 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     bool alive = false;
     Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
     V3 T = v3(1, 1, 1);
-    Rng rng{0u};
+    Rng rng{0u, 0u};
     int depth = 0, pix = lane;
+    // the pixel word of the random stream (include/rt_rng.h), set again wherever draws are made instead of held in a register
+    auto pixel_word = [&](int px) {
+        const uint32_t u = (uint32_t)px;
+        return px < 0 ? u & 0x7fffffffu : (uint32_t)(tile_y * 8 * A.nx + tile_x * 8) + (__umul24(u >> 3, (uint32_t)A.nx) + (u & 7u));
+    };
     rtf::Walk w;
     rtf::walk_start(w, r, RT_FLT_MAX, false);
 #ifdef RT_COUNT_WALK
@@ -830,6 +846,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
             RT_COUNT(7, waiting);
             if (waiting) {
                 const bool hit_any = w.best_prim >= 0;
+                rng.w = pixel_word(pix);
                 rtf::Surface sf;
                 sf.p = r.o; // a miss ends the path; shade still writes the (dead) ray from it
                 if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
@@ -875,7 +892,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                     const int sub = q - qs * A.sub_samples;
                     const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
                     if (col < A.nx && row < A.ny) {
-                        rng.start(rt_path_key(A.seed, (uint32_t)(row * A.nx + col), (uint32_t)(sample * A.sub_samples + sub)));
+                        rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), (uint32_t)(row * A.nx + col));
                         const int j = A.ny - 1 - row;
                         const float u = (float(col) + rng.next()) * inv_nx;
                         const float v = (float(j) + rng.next()) * inv_ny;
@@ -910,7 +927,10 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
         if (__popcll(__ballot(at_leaf)) >= A.leaf_batch || !__any(w.cur >= 0)) {
             RT_COUNT(1, at_leaf);
             RT_COUNT_WAVE(5, __any(at_leaf));
-            if (at_leaf) rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
+            if (at_leaf) {
+                rng.w = pixel_word(pix); // a constant_medium draws (src/volume.h:43)
+                rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
+            }
         }
     }
 
@@ -928,7 +948,7 @@ __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n,
     const int k = alive ? i : 0;
     const float *f = rays + 7 * (size_t)k;
     Ray r{v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), f[6]};
-    Rng rng{rt_path_key(seed, (uint32_t)k, 0u)};
+    Rng rng{rt_path_key(seed, 0u), (uint32_t)k};
     extern __shared__ int bvh_stacks[]; // [4][stack_levels][64]
     int *stack = &bvh_stacks[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * stack_levels * 64 + (threadIdx.x & 63)];
     float t;

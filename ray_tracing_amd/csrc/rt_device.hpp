@@ -76,13 +76,15 @@ struct Onb { // src/vec3.h:195-224
 };
 
 // per-path random stream, include/rt_rng.h
-// rt_draw(key, n) hashes key + n * 0x9E3779B9; the sum is carried instead of recomputed.
+// rt_draw(key, pixel, n) hashes key + n * 0x9E3779B9 with the pixel index folded in; the sum is carried instead of
+// recomputed.  `w` is the pixel index: a kernel that cannot spare the register between two places that draw sets it
+// again (a pure function of the tile and the lane's place in it) instead of carrying it.
 struct Rng {
-    uint32_t x;
-    RT_DEV void start(uint32_t key) { x = key; }
+    uint32_t x, w;
+    RT_DEV void start(uint32_t key, uint32_t pixel) { x = key, w = pixel; }
     RT_DEV float next()
     {
-        const uint32_t h = rt_mix32(x);
+        const uint32_t h = rt_mix32_w(x, w);
         x += 0x9E3779B9U;
         return (float)(h >> 8) * (1.0f / 16777216.0f);
     }

@@ -32,6 +32,11 @@ def load():
         lib.orc_trace_rays.argtypes = [D, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]
         lib.orc_counters_get.argtypes = [C.c_void_p]
         lib.orc_set_perlin_table.argtypes = [C.c_void_p]
+        lib.orc_rng_draws.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        lib.orc_rng_key.restype = C.c_uint32
+        lib.orc_rng_key.argtypes = [C.c_uint32, C.c_uint32]
+        lib.orc_rng_mix_w.restype = C.c_uint32
+        lib.orc_rng_mix_w.argtypes = [C.c_uint32, C.c_uint32]
         F = C.POINTER(C.c_float)
         lib.orc_kat_aabb_hit.argtypes = [F, F, F, F, C.c_float, C.c_float]
         lib.orc_kat_sphere_hit.argtypes = [F, F, F, C.c_float, C.c_float, C.c_float, F]
@@ -89,6 +94,13 @@ def trace_rays(host_scene, rays, t_min=0.001, t_max=FLT_MAX, seed=0):
     load().orc_trace_rays(host_scene.desc, rays.shape[0], rays.ctypes.data_as(C.c_void_p), t_min, t_max, seed,
                           hits.ctypes.data_as(C.c_void_p))
     return hits
+
+
+def rng_draws(seed, pixel, sample, n):
+    """Draws 0..n-1 of the path (seed, pixel, sample): include/rt_rng.h as the oracle compiled it."""
+    out = np.zeros(n, dtype=np.float32)
+    load().orc_rng_draws(seed, pixel, sample, n, out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def counters(reset=False):

@@ -332,22 +332,50 @@ def test_cornell_4k_rank_share_of_baseline_config_4():
     assert np.allclose(m_full, m_small, rtol=0.03), (m_full, m_small)
 
 
-def test_pixel_noise_falls_as_one_over_spp_up_to_65536():
-    """The per-path random stream is keyed by 32 bits (include/rt_rng.h): keys are unique within a pixel, but a 65 536-spp
-    render of this image draws 2.7e8 keys, so paths of DIFFERENT pixels share streams.  That must not show as a noise floor:
-    the mean squared difference of two renders over disjoint sample ranges (same seed), times spp, must stay what it is at
-    a few hundred samples.  (Caustic pixels make that product noisy, about +-25 % from size to size; a floor at the level of
-    N samples would multiply it by 65536 / N.)"""
-    n = 64
+def test_identical_rays_at_different_indices_draw_different_numbers():
+    """include/rt_rng.h on the device: a path's stream is keyed by (key, pixel), and for rt_trace_rays the pixel word is the
+    ray's index.  4096 copies of ONE ray through the smoke boxes of cornell_box_volumes (constant_medium::hit draws its
+    free-flight distance, src/volume.h:43) must scatter at 4096 different distances, the same ones as the oracle on the same
+    stream, on both GPU paths; another seed gives other distances."""
+    hs = HostScene("cornell_box_volumes", 1.0)
+    sc = Scene(hs, 0)
+    one = np.array([[278, 278, -800, -0.05, -0.12, 1, 0]], dtype=np.float32)
+    rays = np.tile(one, (4096, 1))
+    cpu = O.trace_rays(hs, rays, seed=5)
+    d = hs.desc.contents
+    iso = np.array([d.materials[i].kind == _capi.RT_MAT_ISOTROPIC for i in range(d.n_materials)])
+    in_medium = (cpu["material"] >= 0) & iso[np.maximum(cpu["material"], 0)]
+    assert in_medium.mean() > 0.3  # the ray does cross a smoke box, and a good part of the copies scatter inside it
+    for path in (_capi.RT_PATH_EXACT, _capi.RT_PATH_FAST):
+        sc.set_path(trace=path)
+        g = api.trace_rays(sc, rays, seed=5)
+        gm = (g["material"] >= 0) & iso[np.maximum(g["material"], 0)]
+        assert (gm == in_medium).mean() > 0.995
+        both = gm & in_medium
+        assert np.allclose(g["t"][both], cpu["t"][both], rtol=1e-4)
+        assert len(np.unique(g["t"][gm])) > 0.99 * gm.sum()  # no two indices share a stream
+        other = api.trace_rays(sc, rays, seed=6)
+        om = (other["material"] >= 0) & iso[np.maximum(other["material"], 0)]
+        assert not np.allclose(other["t"][both & om], g["t"][both & om], rtol=1e-4)
+    sc.close()
+
+
+@pytest.mark.parametrize("n,spps", [(64, (256, 1024, 4096, 65536)), (256, (256, 4096, 65536))])
+def test_pixel_noise_falls_as_one_over_spp_up_to_65536(n, spps):
+    """A path's stream is keyed by 64 bits, (sample, seed) and the pixel (include/rt_rng.h; round 2: 32 bits in all, so at
+    this test's 256 x 256 x 131 072 = 8.6e9 paths every key was shared by two paths of different pixels).  Shared or
+    correlated streams would show as a noise floor: the mean squared difference of two renders over disjoint sample
+    ranges (same seed), times spp, must stay what it is at a few hundred samples.  (Caustic pixels make that product
+    noisy, about +-25 % from size to size; a floor at the level of N samples would multiply it by 65536 / N.)"""
     sc = Scene(HostScene("cornell_box", 1.0), 0)
     v = {}
-    for spp in (256, 1024, 4096, 65536):
+    for spp in spps:
         a = gpu_render(sc, n, n, 0, spp, seed=77)[..., 1:] / spp
         b = gpu_render(sc, n, n, spp, 2 * spp, seed=77)[..., 1:] / spp
         v[spp] = float(((a - b) ** 2).mean()) * spp
     sc.close()
     print({k: f"{x:.3f}" for k, x in v.items()})
-    low = np.mean([v[256], v[1024], v[4096]])
+    low = np.mean([v[k] for k in spps[:-1]])
     assert 0.4 * low <= v[65536] <= 1.6 * low, v
 
 
