@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Cornell box 1024x1024, 1024 spp, depth 50 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c5] [--no-extra] [--no-cpu]
 
 With --gpus N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a child (before
@@ -9,15 +9,24 @@ torch or HIP is touched here; never an exec), relays the child's output and retu
 torch.distributed.run itself (WORLD_SIZE set) it is one rank.
 
 One "step" is one complete image: every rank renders its disjoint range of the samples into its own float4
-accumulator (rt_render), the accumulators are summed onto rank 0 with one RCCL reduce (N > 1 only), and rank 0
-resolves to 8 bits (rt_resolve).  The scene is uploaded once before the timed region (inputs resident in HBM).
+accumulator (rt_render), the accumulators are summed onto rank 0 with one RCCL reduce (N > 1 only), rank 0
+resolves to 8 bits (rt_resolve) and copies the 8-bit image to (pinned) host memory: SURVEY.md 8d's seconds-to-image ends
+with the resolved image on the host.  The scene is uploaded once before the timed region (inputs resident in HBM).
 The total work is fixed, so the scaling is strong.  Prints ONE JSON line on rank 0.
 
 value       = nx*ny*spp / seconds per step / 1e6   [Mpaths/s, whole job]
 roofline    = the render kernel against its bound.  Cornell box, random spheres, Next-Week final: FP32 vector peak
               (MFMA is unused on purpose: no dense contraction on this path): algorithmic FLOP per launch (DESIGN.md:
               kFLOP per path x paths per launch) / the kernel's duration from HIP events on the launch stream.
-              1M-sphere field: HBM (algorithmic tree + leaf bytes per path, DESIGN.md, x paths per launch / duration).
+              1M-sphere field: HBM.  `achieved` there is what the counters saw reach the memory side of the L2 (bytes per
+              path from the committed rocprofv3 passes x paths per launch / duration): the walks' algorithmic bytes
+              (nodes and leaves touched x 32 B) are mostly served by the L1s and the L2 and stand beside it as
+              roofline.algorithmic; a roofline fraction is never above 1.
+              roofline.counters: what the committed profile of that workload says about the same kernel (vector issue,
+              lanes on, waiting, the rays per path the GPU really traces): profiles/counters.json.
+other_configs = (N = 1, unless --no-extra) BASELINE configs 1, 3 and 5 timed in the same process after the headline's
+              steps, 1 warm-up + at least 2 steps each (as many as fill a third of a second), the same way: their numbers in
+              the driver's own record.
 cpu_baseline= the compiled reference (oracle/_ref/rt_ref, kind "reference") or, if that binary is not in
               the tree, the oracle port, timed on this host on a bounded sample of the same workload
 """
@@ -128,6 +137,18 @@ def traffic_from_profile(cfg):
         return json.load(f)
 
 
+def counters_from_profile(cfg):
+    """profiles/counters.json: per workload what the committed rocprofv3 passes and the census builds say about its render
+    kernel -- valu_issue_frac (vector instructions x 2 cycles over SIMDs x kernel cycles), lane_util (thread cycles / 64 x
+    vector instructions), wait_frac (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES), gpu_rays_per_path (rays the kernel traces per
+    path: it ends a path at weight zero, the reference carries it on) -- with the profile each number came from."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(cfg)
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -158,6 +179,7 @@ def parse_args(argv):
     ap.add_argument("--spp", type=int, default=None, help=argparse.SUPPRESS)  # for quick experiments only
     ap.add_argument("--size", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip configs 1, 3, 5 after the headline (other_configs)")
     ap.add_argument("--rehearse-rccl", action="store_true", help=argparse.SUPPRESS)  # see main()
     return ap.parse_args(argv)
 
@@ -196,106 +218,158 @@ def main(argv=None):
         dist.init_process_group(backend, **({} if hook else {"device_id": dev}))
     n_ranks_seen = dist.get_world_size() if grouped else 1
 
-    cfg = dict(CONFIGS[a.config])
-    nx = ny = None
-    if a.size:
-        nx, ny = a.size, max(1, a.size * cfg["ny"] // cfg["nx"])
-    else:
-        nx, ny = cfg["nx"], cfg["ny"]
-    spp = a.spp or cfg["spp"]
-    s0, s1 = D.sample_range(rank, world, spp)  # disjoint sample ranges
+    def measure(config, steps, warmup, spp_override=None, size_override=None):
+        """K timed images of one workload; returns rank 0's report (None on the other ranks)."""
+        cfg = dict(CONFIGS[config])
+        if size_override:
+            nx, ny = size_override, max(1, size_override * cfg["ny"] // cfg["nx"])
+        else:
+            nx, ny = cfg["nx"], cfg["ny"]
+        spp = spp_override or cfg["spp"]
+        s0, s1 = D.sample_range(rank, world, spp)  # disjoint sample ranges (SURVEY.md 8e)
 
-    if hook:
-        mod, fn = hook.split(":")
-        render, resolve, sync, last_ms, kernel_name = getattr(__import__(mod), fn)(cfg["scene"], nx, ny, DEPTH)
-    else:
-        from ray_tracing_amd import _capi, api
-        scene = api.Scene(api.HostScene(cfg["scene"], nx / ny), local)
-        accum_buf = torch.empty((ny, nx, 4), dtype=torch.float32, device=dev)
-        image = torch.empty((ny, nx), dtype=torch.int32, device=dev)
+        if hook:
+            mod, fn = hook.split(":")
+            render, resolve, sync, last_ms, kernel_name = getattr(__import__(mod), fn)(cfg["scene"], nx, ny, DEPTH)
+            scene = None
+        else:
+            from ray_tracing_amd import _capi, api
+            scene = api.Scene(api.HostScene(cfg["scene"], nx / ny), local)
+            accum_buf = torch.empty((ny, nx, 4), dtype=torch.float32, device=dev)
+            image = torch.empty((ny, nx), dtype=torch.int32, device=dev)
+            host_image = torch.empty((ny, nx), dtype=torch.int32, pin_memory=True)  # where the image ends up (SURVEY.md 8d)
 
-        def render(b, e):
-            return api.render(scene, accum_buf, nx, ny, b, e, max_depth=DEPTH, seed=0)
+            def render(b, e):
+                return api.render(scene, accum_buf, nx, ny, b, e, max_depth=DEPTH, seed=0)
 
-        def resolve(acc):
-            return api.resolve(acc, image)
+            def resolve(acc):
+                api.resolve(acc, image)
+                host_image.copy_(image, non_blocking=True)  # in stream order after the resolve; the fence below waits for it
+                return host_image
 
-        sync = torch.cuda.synchronize
-        last_ms = scene.last_render_ms
+            sync = torch.cuda.synchronize
+            last_ms = scene.last_render_ms
 
-        def kernel_name():
-            if scene.info(_capi.RT_INFO_LAST_RENDER_PATH) != _capi.RT_PATH_FAST:
-                return "render_kernel_uniform / render_kernel_lanes (exact path)"
-            # record table without textures -> the block kernel; no record table -> the per-lane walk
-            return "render_fast_block_kernel" if scene.info(_capi.RT_INFO_RECORDS) > 0 and cfg["scene"] == "cornell_box" else \
-                ("render_fast_kernel" if scene.info(_capi.RT_INFO_RECORDS) > 0 else "render_fastlanes_kernel")
+            def kernel_name():
+                if scene.info(_capi.RT_INFO_LAST_RENDER_PATH) != _capi.RT_PATH_FAST:
+                    return "render_kernel_uniform / render_kernel_lanes (exact path)"
+                # record table without textures -> the block kernel; no record table -> the per-lane walk
+                return "render_fast_block_kernel" if scene.info(_capi.RT_INFO_RECORDS) > 0 and cfg["scene"] == "cornell_box" else \
+                    ("render_fast_kernel" if scene.info(_capi.RT_INFO_RECORDS) > 0 else "render_fastlanes_kernel")
 
-    def step():
-        acc = render(s0, s1)
-        D.reduce_accumulators(acc, 0, even_alone=grouped)
-        if rank == 0:
-            resolve(acc)
+        def step():
+            acc = render(s0, s1)
+            D.reduce_accumulators(acc, 0, even_alone=grouped)
+            if rank == 0:
+                resolve(acc)
 
-    def fence():
-        sync()
+        def fence():
+            sync()
+            if grouped:
+                dist.barrier()
+            sync()
+
+        for _ in range(warmup):
+            step()
+        fence()
+        if steps is None:
+            # other_configs: enough images to time about a third of a second (at least 2, at most 50): a launch of a few
+            # milliseconds is otherwise timed while the clocks are still coming up after the host-side scene build
+            steps = max(2, min(50, int(0.35 / max(last_ms() * 1e-3, 1e-4))))
+            for _ in range(min(steps, 5)):
+                step()
+            fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        # kernel duration from the HIP events rt_render records on its launch stream (last step; steps are identical)
+        k_ms = last_ms()
+        t = torch.tensor([dt, k_ms], dtype=torch.float64, device=dev)
         if grouped:
-            dist.barrier()
-        sync()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, k_ms = float(t[0]), float(t[1])
+        kname = kernel_name()
+        if scene is not None:
+            scene.close()
+        if rank != 0:
+            return None
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    # kernel duration from the HIP events rt_render records on its launch stream (last step; steps are identical)
-    k_ms = last_ms()
-    t = torch.tensor([dt, k_ms], dtype=torch.float64, device=dev)
-    if grouped:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt, k_ms = float(t[0]), float(t[1])
-
-    if rank == 0:
-        sec_per_step = dt / a.steps
+        sec_per_step = dt / steps
         paths = nx * ny * spp
         value = paths / sec_per_step / 1e6
         paths_per_launch = nx * ny * (s1 - s0)
         counts = {} if cfg.get("no_counts") else load_work_counts().get(cfg["scene"], {})
+        tr = traffic_from_profile(config) or {}
+        roof = {"bound": cfg["bound"]}
         if cfg["bound"] == "hbm":
-            per = cfg.get("bytes_per_path") or counts.get("bytes_per_path")
-            achieved = paths_per_launch * per / (k_ms * 1e-3) / 1e9 if per else None
-            peak, unit, note = HBM_PEAK_GBS, "GB/s", ("algorithmic bytes: tree nodes visited x 32 B + leaves tested x 32 B per path; "
-                                                "most are served by the L1s / L2 (l2_hit), so achieved may exceed the HBM peak: "
-                                                "traffic = what reached the memory side of the L2 (profiles/c5_traffic.json)")
+            # what the counters saw reach the memory side of the L2, per path of the profiled launch, x this launch's paths
+            per_path_hbm = tr["hbm_bytes_per_launch"] / tr["paths_per_launch"] if tr.get("paths_per_launch") else None
+            per_alg = cfg.get("bytes_per_path") or counts.get("bytes_per_path")
+            achieved = paths_per_launch * per_path_hbm / (k_ms * 1e-3) / 1e9 if per_path_hbm else None
+            peak, unit, per = HBM_PEAK_GBS, "GB/s", per_path_hbm
+            traffic = None if per_path_hbm is None else int(paths_per_launch * per_path_hbm)
+            note = ("achieved = HBM-side bytes per path from the committed rocprofv3 passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction; "
+                    "profiles/c5_traffic.json) x paths per launch / kernel time; the walks' algorithmic bytes are mostly L1 / L2 hits (l2_hit)")
+            if per_alg:
+                rate = paths_per_launch * per_alg / (k_ms * 1e-3) / 1e9
+                roof["algorithmic"] = {"bytes_per_path": per_alg, "bytes_per_launch": int(paths_per_launch * per_alg), "rate": round(rate, 1),
+                                       "unit": "GB/s", "note": "tree nodes visited x 32 B + leaves tested x 32 B; served by L1 / L2 / Infinity "
+                                       "Cache as well as HBM, so this rate is not bounded by the HBM peak"}
         else:
             per = cfg.get("flop_per_path") or counts.get("flop_per_path")
             achieved = paths_per_launch * per / (k_ms * 1e-3) / 1e12 if per else None
             peak, unit = FP32_VECTOR_PEAK_TFLOPS, "TFLOP/s"
-            note = "no dense contraction on this path: MFMA unused, FP32 vector peak = FP32 matrix peak"
+            traffic = tr.get("hbm_bytes_per_launch")
+            note = ("no dense contraction on this path: MFMA unused, FP32 vector peak = FP32 matrix peak; per_path = the REFERENCE's "
+                    "algorithmic work (SURVEY.md 8d costs x its own operation counts), which prices rays the kernel does not trace: "
+                    "see counters.gpu_rays_per_path against the reference's rays per path")
+        roof.update({"achieved": None if achieved is None else round(achieved, 4), "peak": peak, "unit": unit,
+                     "frac": None if achieved is None else round(achieved / peak, 5), "traffic": traffic, "l2_hit": tr.get("l2_hit"),
+                     "kernel": kname, "kernel_ms": round(k_ms, 3), "per_path": None if per is None else round(per, 1), "note": note})
+        ctr = counters_from_profile(config)
+        if ctr:
+            roof["counters"] = ctr
+        ref_rays = (counts.get("reference_tree_per_path") or {}).get("rays")
+        if ref_rays:
+            roof["reference_rays_per_path"] = ref_rays
+        if tr.get("lane_steps_per_path") and tr.get("gather_rate_lane_steps_per_s"):
+            # config 5: the per-lane walk beside the measured rate of bare chains of dependent 32-byte gathers at the walk's
+            # locality (tools/ubench/gather_chain.hip).  A comparison, not a limit: the ubench's access pattern is harsher than the
+            # walk's (profiles/r02_gather_chain_ubench.txt), so no fraction is printed
+            rate = paths_per_launch * tr["lane_steps_per_path"] / (k_ms * 1e-3)
+            roof["gather"] = {"achieved": round(rate, 1), "ubench": tr["gather_rate_lane_steps_per_s"], "unit": "lane-steps/s (32 B each)"}
+        return {"cfg": cfg, "nx": nx, "ny": ny, "spp": spp, "steps": steps, "value": value, "sec_per_step": sec_per_step, "roofline": roof}
+
+    m = measure(a.config, a.steps, a.warmup, a.spp, a.size)
+    if rank == 0:
+        cfg, nx, ny, spp = m["cfg"], m["nx"], m["ny"], m["spp"]
         partition = (f"disjoint spp ranges over {world} GPUs + one RCCL sum-reduce of float4[{nx}*{ny}] onto rank 0" if world > 1 else
                      "one GPU renders every sample; no reduce at N=1" + (" (rehearsal: a one-rank RCCL reduce per step)" if grouped else ""))
         out = {
             "metric": "Mpaths/sec (node), Cornell box 1024x1024 1024spp depth 50" if a.config == "c2" else
                       f"Mpaths/sec (node), {cfg['scene']} {cfg['nx']}x{cfg['ny']} {cfg['spp']}spp depth {DEPTH}",
-            "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(sec_per_step * 1e3, 3), "seconds_to_image": round(sec_per_step, 4),
+            "value": round(m["value"], 2), "unit": "Mpaths/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(m["sec_per_step"] * 1e3, 3), "seconds_to_image": round(m["sec_per_step"], 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not hook else "synthetic (CPU test hook: launch/partition/reduce logic only, not a measurement)",
-            "config": {"workload": f"{cfg['scene']} {nx}x{ny} {spp}spp depth {DEPTH} ({cfg['name']})", "partition": partition},
-            "roofline": {"bound": cfg["bound"], "achieved": None if achieved is None else round(achieved, 4), "peak": peak,
-                         "unit": unit, "frac": None if achieved is None else round(achieved / peak, 5),
-                         "traffic": (traffic_from_profile(a.config) or {}).get("hbm_bytes_per_launch"),
-                         "l2_hit": (traffic_from_profile(a.config) or {}).get("l2_hit"), "kernel": kernel_name(), "kernel_ms": round(k_ms, 3),
-                         "per_path": per, "note": note},
+            "config": {"workload": f"{cfg['scene']} {nx}x{ny} {spp}spp depth {DEPTH} ({cfg['name']})", "partition": partition,
+                       "seconds_to_image": "render + reduce + resolve + copy of the 8-bit image to pinned host memory"},
+            "roofline": m["roofline"],
         }
-        tr = traffic_from_profile(a.config) or {}
-        if tr.get("lane_steps_per_path") and tr.get("gather_limit_lane_steps_per_s"):
-            # config 5: the per-lane walk against the measured throughput of dependent 32-byte gathers (tools/ubench/gather_chain.hip)
-            rate = paths_per_launch * tr["lane_steps_per_path"] / (k_ms * 1e-3)
-            out["roofline"]["gather"] = {"achieved": round(rate, 1), "limit": tr["gather_limit_lane_steps_per_s"], "unit": "lane-steps/s (32 B each)",
-                                         "frac": round(rate / tr["gather_limit_lane_steps_per_s"], 4)}
+    # BASELINE configs 1, 3 and 5 in the same process (one GPU only; the headline's fields above are not touched)
+    if world == 1 and a.config == "c2" and not a.no_extra and not hook and not a.spp and not a.size:
+        others = []
+        for name in ("c1", "c3", "c5"):
+            o = measure(name, None, 1)
+            c = o["cfg"]
+            others.append({"workload": f"{c['scene']} {o['nx']}x{o['ny']} {o['spp']}spp depth {DEPTH} ({c['name']})",
+                           "value": round(o["value"], 2), "unit": "Mpaths/s", "steps": o["steps"], "warmup": 1,
+                           "ms_per_step": round(o["sec_per_step"] * 1e3, 3), "kernel": o["roofline"]["kernel"],
+                           "kernel_ms": o["roofline"]["kernel_ms"], "roofline": o["roofline"]})
+        out["other_configs"] = others
+    if rank == 0:
         if world == 1 and not a.no_cpu and not hook:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

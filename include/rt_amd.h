@@ -233,6 +233,24 @@ int rt_sample_range(int32_t rank, int32_t world, int32_t sample_begin, int32_t s
 int rt_render_multi_to_host(const rt_scene_desc* desc, const int32_t* devices, int32_t n_devices,
                             const rt_render_params* params, uint32_t flags, float* h_accum, uint32_t* h_rgba8);
 
+/* The same with the set-up done ONCE: the reference builds its thread pool once and renders with it
+ * (src/main.cpp:523-561); a context holds a scene and a stream per device, ONE RCCL communicator (ncclCommInitAll) and
+ * the per-device accumulators (grown to the largest image asked for, then kept), so that the time of an image is
+ * render + reduce + resolve + copy, not communicator set-up.  rt_render_multi_to_host is create + one image + destroy.
+ *   rt_multi_create          flags: RT_MULTI_REDUCE_ALWAYS as above.  On failure nothing is left allocated.
+ *   rt_multi_render_to_host  one image; h_accum and h_rgba8 as above, either may be NULL (not both).  Blocking; one
+ *                            image at a time per context (calls on one context are serialised by a lock).  After a
+ *                            failed call the streams have been drained; the context may be used again or destroyed.
+ *   rt_multi_set_option      rt_scene_set_option on every device's scene.
+ *   rt_multi_last_render_ms  the longest of the devices' render kernels of the latest image (rt_last_render_ms).
+ *   rt_multi_destroy         waits for every stream, then frees communicator, buffers, streams and scenes. */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc* desc, const int32_t* devices, int32_t n_devices, uint32_t flags, rt_multi** out);
+int rt_multi_render_to_host(rt_multi* ctx, const rt_render_params* params, float* h_accum, uint32_t* h_rgba8);
+int rt_multi_set_option(rt_multi* ctx, int option, int value);
+int rt_multi_last_render_ms(rt_multi* ctx, float* ms_out);
+void rt_multi_destroy(rt_multi* ctx);
+
 /* ------------------------------------------------------------------ */
 /* Closest-hit queries (the parity surface)                             */
 /* ------------------------------------------------------------------ */
@@ -256,7 +274,10 @@ typedef struct rt_hit {
 
 /* hitable::hit on the world (src/main.cpp:94: world->hit(r, 0.001f, FLT_MAX, rec))
  * for n rays of 7 floats each.  `seed` keys the draws constant_medium::hit
- * makes (src/volume.h:43); it is unused for scenes without media. */
+ * makes (src/volume.h:43); it is unused for scenes without media.
+ * On RT_PATH_FAST with a record table (RT_INFO_RECORDS > 0) t_min must be positive (the scan orders hits by the bits of
+ * t, which order like t only for t > 0): t_min <= 0 or NaN is rejected with RT_ERR_INVALID; use RT_PATH_EXACT for such
+ * ranges.  The reference itself only ever passes 0.001f (src/main.cpp:94) and 0.0001f (src/plane.h:81). */
 int rt_trace_rays(rt_scene* scene, int32_t n, const float* h_rays, float t_min, float t_max,
                   uint32_t seed, rt_hit* h_hits_out);
 
@@ -265,7 +286,9 @@ int rt_trace_rays(rt_scene* scene, int32_t n, const float* h_rays, float t_min, 
  * library (RT_TRACE_NOALLOC_MAX_RAYS x 76 bytes = 4.75 MiB, held by every GPU the library runs on until the
  * process ends) instead of two hipMalloc'ed buffers per call.  Calls no hipMalloc / hipFree.  n above
  * RT_TRACE_NOALLOC_MAX_RAYS is rejected with RT_ERR_INVALID.  Every call on a GPU shares that GPU's array:
- * calls that overlap on one GPU (two host threads, two scenes on the same device) race; serialise them.
+ * the library serialises the calls of ONE process on a GPU with a per-device lock (copy in, kernel, copy out under
+ * it); calls from different processes have arrays of their own.  Work the caller queues itself on other streams
+ * must not touch the array.
  * No counterpart in the reference (it has no device and no staging); it exists for callers that cannot allocate. */
 #define RT_TRACE_NOALLOC_MAX_RAYS 65536
 int rt_trace_rays_noalloc(rt_scene* scene, int32_t n, const float* h_rays, float t_min, float t_max,

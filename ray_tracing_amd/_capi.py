@@ -106,6 +106,11 @@ PROTOTYPES = {
     "rt_sample_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rt_render_multi_to_host": (C.c_int, [C.POINTER(rt_scene_desc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(rt_render_params),
                                           C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rt_multi_create": (C.c_int, [C.POINTER(rt_scene_desc), C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "rt_multi_render_to_host": (C.c_int, [C.c_void_p, C.POINTER(rt_render_params), C.c_void_p, C.c_void_p]),
+    "rt_multi_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rt_multi_last_render_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rt_multi_destroy": (None, [C.c_void_p]),
     "rt_camera_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "rt_trace_rays_noalloc": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),

@@ -14,7 +14,8 @@
 //     (src/main.cpp:270-326) from rt_camera_rays + rt_trace_rays at pixel centres; the reference's own -p
 //     dumps buffers it never fills;
 //   * extra options, absent from the reference: --scene NAME, --seed N, --device N, --path auto|exact|fast, and
-//     --devices LIST [--reduce-always] (the samples shared by several GPUs of the node, one RCCL sum-reduce), and
+//     --devices LIST [--reduce-always] [--repeat K] (the samples shared by several GPUs of the node, one RCCL sum-reduce;
+//     the multi-GPU context is built once and K images are rendered on it), and
 //     --accum FILE [--save-every N]: progressive render with save and resume, which the reference lists as not done
 //     (TODO.txt:5-17).  The file holds the float sums and the number of samples in them; -s is the TOTAL wanted.
 // No CPU rendering path exists here: without a HIP device the program stops with the library's error.
@@ -72,6 +73,7 @@ Opt g_opts[] = {
     {"", "save-every", "With --accum: also save after every N samples", false, "0", nullptr, "", 0},
     {"", "devices", "GPUs that share the samples, e.g. 0-7 or 0,2,5 (one RCCL sum-reduce onto the first)", true, "", nullptr, "", 0},
     {"", "reduce-always", "With --devices: run the RCCL reduce on one device too", false, "0", "1", "", 0},
+    {"", "repeat", "With --devices: render the image K times on one context and print each image's time", false, "1", nullptr, "", 0},
 };
 const int g_nopts = sizeof(g_opts) / sizeof(g_opts[0]);
 
@@ -468,11 +470,31 @@ int main(int argc, char **argv)
             image[k] = pack(c[0], c[1], c[2]);
         }
     } else if (!devices.empty()) {
-        // the samples shared by several GPUs: disjoint sample ranges, one RCCL sum-reduce, resolve on the first (include/rt_amd.h)
+        // the samples shared by several GPUs: disjoint sample ranges, one RCCL sum-reduce, resolve on the first (include/rt_amd.h).
+        // The context -- scenes, streams, accumulators, ONE communicator -- is built once, like the reference's thread pool
+        // (src/main.cpp:523-561); --repeat K renders the image K times on it and prints what each one took, so that a
+        // seconds-to-image is render + reduce + resolve + copy and not communicator set-up.
         rp.sample_begin = 0, rp.sample_end = ns;
-        check(rt_render_multi_to_host(rt_host_scene_desc(host), devices.data(), (int32_t)devices.size(), &rp,
-                                      opt_int("reduce-always") ? RT_MULTI_REDUCE_ALWAYS : 0u, accum.data(), image.data()),
-              "rt_render_multi_to_host");
+        rt_multi *ctx = nullptr;
+        auto t_ctx = std::chrono::high_resolution_clock::now();
+        check(rt_multi_create(rt_host_scene_desc(host), devices.data(), (int32_t)devices.size(),
+                              opt_int("reduce-always") ? RT_MULTI_REDUCE_ALWAYS : 0u, &ctx),
+              "rt_multi_create");
+        const int repeat = std::max(1, opt_int("repeat"));
+        if (repeat > 1)
+            printf("context on %zu device(s): %.2fms\n", devices.size(),
+                   std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_ctx).count());
+        for (int k = 0; k < repeat; ++k) {
+            auto t_img = std::chrono::high_resolution_clock::now();
+            check(rt_multi_render_to_host(ctx, &rp, accum.data(), image.data()), "rt_multi_render_to_host");
+            if (repeat > 1) {
+                float kernel_ms = 0.0f;
+                check(rt_multi_last_render_ms(ctx, &kernel_ms), "rt_multi_last_render_ms");
+                printf("image %d/%d: %.2fms (slowest device's render kernel %.2fms)\n", k + 1, repeat,
+                       std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_img).count(), kernel_ms);
+            }
+        }
+        rt_multi_destroy(ctx);
         printf("%d/%d : %.2f%%\r", ns, ns, 100.0f);
     } else {
         rp.sample_begin = 0, rp.sample_end = ns;

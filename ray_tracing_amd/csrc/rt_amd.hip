@@ -1025,6 +1025,7 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES]; // 4.75 M
 constexpr int NOALLOC_MAX_DEVICES = 64;
 static std::mutex g_scratch_mutex;
 static void *g_scratch_ptr[NOALLOC_MAX_DEVICES]; // [device]: that device's copy of `scratch`
+static std::mutex g_scratch_in_use[NOALLOC_MAX_DEVICES]; // [device]: held from copy-in to copy-out of one call
 
 // `device` must be current.  Asks the runtime once per device.
 static int scratch_of_device(int device, void **out)
@@ -1154,9 +1155,10 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
     if (ndev < 0) return ndev;
     if (device < 0 || device >= ndev) return rt_fail(RT_ERR_NO_DEVICE, "rt_scene_create: device %d of %d", device, ndev);
     RT_HIP(hipSetDevice(device));
-    void *scratch_ptr = nullptr; // this device's copy of the static staging area, asked for once per device
-    st = scratch_of_device(device, &scratch_ptr);
-    if (st != RT_OK) return st;
+    // this device's copy of the static staging area, asked for once per device.  Only rt_trace_rays_noalloc needs it: a
+    // failure here (a device ordinal beyond the table) is that entry point's to report, not the scene's
+    void *scratch_ptr = nullptr;
+    if (scratch_of_device(device, &scratch_ptr) != RT_OK) scratch_ptr = nullptr;
 
     // one blob, every table 256-byte aligned
     struct part {
@@ -1511,12 +1513,25 @@ static hipError_t launch_trace(rt_scene *s, int32_t n, const float *d_rays, floa
     return hipGetLastError();
 }
 
+// The record-table scan keeps a lane's best hit as the bits of t above a rank key (rtf::Best) and compares them as one
+// unsigned number: that orders like t only for t > 0, which t >= t_min guarantees when t_min is positive.  With
+// t_min <= 0 a hit at negative t (sign bit set) would compare as farther than everything and be dropped, where the exact
+// path and the reference report it; such a range is refused on that path instead of answered differently.
+static int check_trace_range(const rt_scene *s, float t_min, const char *who)
+{
+    if (s->trace_path == RT_PATH_FAST && s->fast_ok && !(t_min > 0.0f))
+        return rt_fail(RT_ERR_INVALID, "%s: t_min = %g on the record-table fast path, which needs t_min > 0 (use RT_PATH_EXACT for this range)", who, (double)t_min);
+    return RT_OK;
+}
+
 extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float t_min, float t_max, uint32_t seed, rt_hit *h_hits)
 {
     if (!s || n < 0 || (n > 0 && (!h_rays || !h_hits))) return rt_fail(RT_ERR_INVALID, "rt_trace_rays: bad argument");
     if (n == 0) return RT_OK;
     if (s->trace_path == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
         return rt_fail(RT_ERR_UNSUPPORTED, "rt_trace_rays: the fast path was requested but cannot run this scene (%s; and no ordered walk)", s->fast_why);
+    const int st = check_trace_range(s, t_min, "rt_trace_rays");
+    if (st != RT_OK) return st;
     RT_HIP(hipSetDevice(s->device));
     const size_t N = (size_t)n;
     float *d_rays = nullptr;
@@ -1535,14 +1550,19 @@ extern "C" int rt_trace_rays(rt_scene *s, int32_t n, const float *h_rays, float 
 extern "C" int rt_trace_rays_noalloc(rt_scene *s, int32_t n, const float *h_rays, float t_min, float t_max, uint32_t seed, rt_hit *h_hits)
 {
     if (!s || n < 0 || (n > 0 && (!h_rays || !h_hits))) return rt_fail(RT_ERR_INVALID, "rt_trace_rays_noalloc: bad argument");
+    int st = RT_OK;
     if (n > RT_TRACE_NOALLOC_MAX_RAYS)
         return rt_fail(RT_ERR_INVALID, "rt_trace_rays_noalloc: %d rays, the static staging area holds %d; split the batch or use rt_trace_rays", n,
                        RT_TRACE_NOALLOC_MAX_RAYS);
     if (n == 0) return RT_OK;
     if (s->trace_path == RT_PATH_FAST && !s->fast_ok && !s->lanes_ok)
         return rt_fail(RT_ERR_UNSUPPORTED, "rt_trace_rays_noalloc: the fast path was requested but cannot run this scene (%s; and no ordered walk)", s->fast_why);
-    if (!s->scratch) return rt_fail(RT_ERR_NO_DEVICE, "rt_trace_rays_noalloc: the scene holds no address of the staging area");
+    if (!s->scratch || s->device < 0 || s->device >= NOALLOC_MAX_DEVICES)
+        return rt_fail(RT_ERR_NO_DEVICE, "rt_trace_rays_noalloc: no staging area on device %d (it serves devices 0..%d)", s->device, NOALLOC_MAX_DEVICES - 1);
+    st = check_trace_range(s, t_min, "rt_trace_rays_noalloc");
+    if (st != RT_OK) return st;
     RT_HIP(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> in_use(g_scratch_in_use[s->device]); // the array is one per GPU: one call at a time on it
     const size_t N = (size_t)n;
     float *d_rays = reinterpret_cast<float *>(s->scratch);
     rt_hit *d_hits = reinterpret_cast<rt_hit *>(s->scratch + NOALLOC_HITS_OFFSET);

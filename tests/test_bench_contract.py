@@ -31,6 +31,45 @@ def test_bench_line_has_the_contract_fields():
     assert out["n_ranks_seen"] == 1 and "no reduce at N=1" in out["config"]["partition"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["c1", "c3", "c5"])
+def test_every_config_prints_a_roofline_fraction_below_one(config):
+    """BASELINE configs 1, 3 and 5 at a tiny sample count: the line carries a roofline fraction in (0, 1) -- for config 5 the
+    counters' HBM-side bytes, with the walks' algorithmic bytes as a side field -- and the committed profile's counters."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "1", "--spp", "4",
+                        "--no-cpu"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    r = out["roofline"]
+    assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4, r
+    assert r["bound"] == ("hbm" if config == "c5" else "valu_fp32")
+    c = r["counters"]
+    for key in ("valu_issue_frac", "lane_util", "wait_frac", "gpu_rays_per_path"):
+        assert 0 < c[key], (key, c)
+    assert c["valu_issue_frac"] < 1 and c["lane_util"] <= 1 and c["wait_frac"] < 1
+    if config == "c5":
+        assert r["algorithmic"]["bytes_per_path"] > r["per_path"] and "frac" not in r["gather"]
+    assert "other_configs" not in out
+
+
+@pytest.mark.gpu
+def test_default_line_carries_configs_1_3_5():
+    """The driver's command (no --config): after the headline's steps the same process times configs 1, 3 and 5 and attaches them
+    as other_configs; the headline's own fields are the contract's."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["metric"].startswith("Mpaths/sec (node), Cornell box 1024x1024 1024spp") and 0 < out["roofline"]["frac"] < 1
+    assert out["roofline"]["counters"]["gpu_rays_per_path"] > 1
+    others = out["other_configs"]
+    assert [o["workload"].split()[0] for o in others] == ["random_spheres", "next_week_final", "sphere_field_1m"]
+    for o in others:
+        assert o["value"] > 0 and o["kernel_ms"] > 0 and 0 < o["roofline"]["frac"] < 1, o
+
+
 def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without torch.distributed.run around it: the parent must start the two ranks itself
     (a child process, before it touches torch or HIP), relay rank 0's single JSON line and return the child's exit code.

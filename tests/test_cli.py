@@ -201,3 +201,56 @@ def test_native_multi_device_render_with_rccl_on_one_device(tmp_path):
     assert (read_png(a) == read_png(b)).mean() > 0.999
     assert run(common + ["-o", b, "--devices", "0,0"]).returncode != 0
     assert run(common + ["-o", b, "--devices", "x"]).returncode != 0
+
+
+@pytest.mark.gpu
+def test_multi_context_renders_image_after_image(tmp_path):
+    """rt_multi_create / rt_multi_render_to_host / rt_multi_destroy: the context (scene, stream, accumulator per device, ONE
+    communicator) is built once and K images rendered on it equal K single-device renders -- different seeds, a larger image
+    after a smaller one (the buffers grow), the 8-bit image alone (h_accum NULL).  One GPU here, so the device list is
+    degenerate; RT_MULTI_REDUCE_ALWAYS makes the one-rank communicator and the reduce run on every image."""
+    import ctypes as C
+    from ray_tracing_amd import _capi, api
+    lib = _capi.load()
+    hs = api.HostScene("cornell_box", 1.0)
+    sc = api.Scene(hs, 0)
+    dev = (C.c_int32 * 1)(0)
+    for flags in (0, _capi.RT_MULTI_REDUCE_ALWAYS):
+        ctx = C.c_void_p()
+        assert lib.rt_multi_create(hs.desc, dev, 1, flags, C.byref(ctx)) == _capi.RT_OK, lib.rt_last_error()
+        for nx, ny, ns, seed in ((48, 48, 6, 1), (48, 48, 6, 2), (80, 80, 4, 3), (32, 32, 9, 4)):
+            want_acc, want_img = api.render_to_host(sc, nx, ny, 0, ns, seed=seed)
+            p = api.make_params(nx, ny, 0, ns, seed=seed)
+            acc = np.zeros((ny, nx, 4), np.float32)
+            img = np.zeros((ny, nx), np.uint32)
+            st = lib.rt_multi_render_to_host(ctx, C.byref(p), acc.ctypes.data_as(C.c_void_p), img.ctypes.data_as(C.c_void_p))
+            assert st == _capi.RT_OK, lib.rt_last_error()
+            assert np.all(acc[..., 0] == ns) and np.allclose(acc, want_acc, rtol=1e-5, atol=1e-6)
+            assert (img == want_img).mean() > 0.999
+            img2 = np.zeros((ny, nx), np.uint32)
+            assert lib.rt_multi_render_to_host(ctx, C.byref(p), None, img2.ctypes.data_as(C.c_void_p)) == _capi.RT_OK
+            assert (img2 == want_img).mean() > 0.999
+            ms = C.c_float()
+            assert lib.rt_multi_last_render_ms(ctx, C.byref(ms)) == _capi.RT_OK and ms.value > 0
+        # a refused image leaves the context usable
+        bad = api.make_params(48, 48, 5, 2)
+        assert lib.rt_multi_render_to_host(ctx, C.byref(bad), acc.ctypes.data_as(C.c_void_p), None) != _capi.RT_OK
+        assert lib.rt_multi_render_to_host(ctx, C.byref(p), None, None) == _capi.RT_ERR_INVALID
+        p = api.make_params(48, 48, 0, 6, seed=1)
+        acc = np.zeros((48, 48, 4), np.float32)
+        assert lib.rt_multi_render_to_host(ctx, C.byref(p), acc.ctypes.data_as(C.c_void_p), None) == _capi.RT_OK
+        assert np.allclose(acc, api.render_to_host(sc, 48, 48, 0, 6, seed=1)[0], rtol=1e-5, atol=1e-6)
+        # options reach every device's scene: the exact path renders the same paths
+        assert lib.rt_multi_set_option(ctx, _capi.RT_OPT_RENDER_PATH, _capi.RT_PATH_EXACT) == _capi.RT_OK
+        assert lib.rt_multi_render_to_host(ctx, C.byref(p), acc.ctypes.data_as(C.c_void_p), None) == _capi.RT_OK
+        assert np.all(acc[..., 0] == 6)
+        lib.rt_multi_destroy(ctx)
+    sc.close()
+    # the executable: --repeat K renders K images on one context and prints each one's time
+    out = str(tmp_path / "r.png")
+    pr = run(["-w", "64", "-h", "40", "-s", "8", "-r", "50", "--seed", "4", "-o", out, "--devices", "0", "--reduce-always", "--repeat", "3"])
+    assert pr.returncode == 0, pr.stderr
+    assert pr.stdout.count("image ") == 3 and "context on 1 device(s)" in pr.stdout
+    one = str(tmp_path / "one.png")
+    assert run(["-w", "64", "-h", "40", "-s", "8", "-r", "50", "--seed", "4", "-o", one]).returncode == 0
+    assert (read_png(out) == read_png(one)).mean() > 0.999

@@ -95,3 +95,26 @@ def test_multi_device_render_rejects_bad_device_lists(cornell_host):
     assert lib.rt_render_multi_to_host(cornell_host.desc, twice, 2, C.byref(p), 0, acc.ctypes.data_as(C.c_void_p), None) == _capi.RT_ERR_INVALID
     assert b"listed twice" in lib.rt_last_error()
     assert lib.rt_render_multi_to_host(cornell_host.desc, twice, 0, C.byref(p), 0, acc.ctypes.data_as(C.c_void_p), None) == _capi.RT_ERR_INVALID
+
+
+def test_multi_context_rejects_bad_arguments_before_any_device_work(cornell_host):
+    """rt_multi_create (the persistent form: scenes, streams, ONE communicator built once): the device list is checked before
+    anything touches a device, a failed create leaves a null handle, and the render call refuses a null context."""
+    import ctypes as C
+    from ray_tracing_amd import _capi, api
+    lib = _capi.load()
+    ctx = C.c_void_p(123)
+    twice = (C.c_int32 * 2)(1, 1)
+    assert lib.rt_multi_create(cornell_host.desc, twice, 2, 0, C.byref(ctx)) == _capi.RT_ERR_INVALID and ctx.value is None
+    assert b"listed twice" in lib.rt_last_error()
+    assert lib.rt_multi_create(cornell_host.desc, twice, 65, 0, C.byref(ctx)) == _capi.RT_ERR_INVALID
+    assert lib.rt_multi_create(cornell_host.desc, twice, 1, 2, C.byref(ctx)) == _capi.RT_ERR_INVALID and b"flags" in lib.rt_last_error()
+    assert lib.rt_multi_create(cornell_host.desc, None, 1, 0, C.byref(ctx)) == _capi.RT_ERR_INVALID
+    assert lib.rt_multi_create(cornell_host.desc, twice, 1, 0, None) == _capi.RT_ERR_INVALID
+    p = api.make_params(8, 8, 0, 2)
+    acc = np.zeros((8, 8, 4), np.float32)
+    assert lib.rt_multi_render_to_host(None, C.byref(p), acc.ctypes.data_as(C.c_void_p), None) == _capi.RT_ERR_INVALID
+    ms = C.c_float()
+    assert lib.rt_multi_last_render_ms(None, C.byref(ms)) == _capi.RT_ERR_INVALID
+    assert lib.rt_multi_set_option(None, 1, 0) == _capi.RT_ERR_INVALID
+    lib.rt_multi_destroy(None)  # a null context is ignored

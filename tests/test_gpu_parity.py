@@ -88,6 +88,32 @@ def test_fast_path_primary_ids_vs_reference(golden, key, nx, ny):
     sc.close()
 
 
+def test_record_table_path_refuses_a_range_that_starts_at_or_below_zero(cornell_host):
+    """The record-table scan orders hits by the bits of t (rtf::Best), which order like t only for t > 0: with t_min <= 0 it
+    would drop hits at negative t that the exact path and the reference report.  Such a range is refused on that path, on both
+    closest-hit entry points, and answered -- like the oracle, bit for bit -- on the exact one."""
+    rng = np.random.default_rng(31)
+    n = 4000
+    o = rng.uniform(1, 554, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays = np.concatenate([o, d, np.zeros((n, 1), np.float32)], axis=1)
+    sc = Scene(cornell_host, 0)
+    for t_min in (0.0, -1000.0):
+        exact = api.trace_rays(sc, rays, t_min=t_min)
+        cpu = O.trace_rays(cornell_host, rays, t_min=t_min)
+        assert np.array_equal(exact["prim_id"], cpu["prim_id"]) and np.array_equal(bits(exact["t"]), bits(cpu["t"]))
+    assert (exact["t"] < 0).mean() > 0.2  # the range really reaches behind the origins
+    sc.set_path(trace=_capi.RT_PATH_FAST)
+    for t_min in (0.0, -1000.0, float("nan")):
+        for noalloc in (False, True):
+            with pytest.raises(api.RtError, match="needs t_min > 0"):
+                api.trace_rays(sc, rays, t_min=t_min, noalloc=noalloc)
+    ok = api.trace_rays(sc, rays, t_min=1e-6)  # any positive start is fine
+    sc.set_path(trace=_capi.RT_PATH_EXACT)
+    assert (ok["prim_id"] == api.trace_rays(sc, rays, t_min=1e-6)["prim_id"]).mean() > 0.999 and (ok["prim_id"] >= 0).mean() > 0.8
+    sc.close()
+
+
 def test_fast_path_agrees_with_exact_path_on_incoherent_rays(cornell_host):
     """Bounce-like rays: the fast path's ids and t against the bit-exact path (itself equal to the oracle,
     test_secondary_rays_bit_exact_vs_oracle) and against the oracle directly.  The rects' and the sphere's t are
