@@ -295,6 +295,36 @@ int rt_trace_rays_noalloc(rt_scene* scene, int32_t n, const float* h_rays, float
                           uint32_t seed, rt_hit* h_hits_out);
 
 /* ------------------------------------------------------------------ */
+/* Known-answer evaluation of single functions on the device            */
+/* ------------------------------------------------------------------ */
+/* Evaluates, for n items of 16 floats each, the device functions behind the reference functions named below, called as
+ * the render kernels call them, and writes 16 floats per item; rt:: is the family of RT_PATH_EXACT, rtf:: the one of
+ * RT_PATH_FAST.  A test surface (tests/test_gpu_kat.py compares with the reference-written vectors of
+ * tests/golden/kat.npz and with the oracle), never on a render path.  Unused inputs are ignored, unused outputs are 0.
+ *   RT_EVAL_LIGHT_PDF   in kind (0 xz_rect, 1 sphere), o[3], v[3], f[5] (rt_prim.f), normal[3]
+ *                       out rt:: pdf_value (src/plane.h:76-91, src/sphere.h:68-83), cosine_pdf::value (src/pdf.h:13-24),
+ *                           then the same two of rtf:: (for the normalised v)
+ *   RT_EVAL_ONB         in n[3]   out rt:: onb u, v, w (src/vec3.h:195-224), unit(n), get_sphere_uv(unit(n)) (src/utils.h:57-68)
+ *   RT_EVAL_ONB_FAST    in n[3], a[3]   out rtf:: onb u, v, w, unit(n), onb.local(a)
+ *   RT_EVAL_OPTICS      in v[3], n[3], ni_over_nt, cosine, ref_idx   out reflect[3], refracted?, refract[3], schlick (src/utils.h:4-30)
+ *   RT_EVAL_PERLIN      in p[3]   out rt:: noise, turb(7) (src/perlin.h:54-136), rtf:: noise, turb
+ *   RT_EVAL_TEXTURE     in index into the scene's textures, u, v, p[3]   out rt:: value[3] (src/texture.h:9-81), rtf:: value[3]
+ *   RT_EVAL_SAMPLERS    in key, pixel (bit patterns of the stream, include/rt_rng.h), o[3]; each sampler from draw 0
+ *                       out rt:: hitable_list::random(o) over the scene's important list[3] (src/hitable_list.h:79-88),
+ *                           random_cosine_direction[3] (src/vec3.h:173-182), random_in_unit_sphere[3], random_in_unit_disk[2]
+ *                           (src/utils.h:32-55), rtf:: unit sphere[3], unit disk[2]
+ *   RT_EVAL_BOUNCE      in ray[7], key, pixel   world->hit() and ONE bounce of color() (src/main.cpp:91-127) at depth 0 of 50, T = 1
+ *                       out hit?, material kind, continues?, scattered direction[3], weight[3] (the throughput factor; the
+ *                           radiance when the path ends), t        -- the EXACT family
+ *   RT_EVAL_BOUNCE_FAST the same through the FAST family (record table or the library's own tree, as rt_render picks)
+ * No counterpart in the reference. */
+enum rt_eval_kind {
+    RT_EVAL_LIGHT_PDF = 1, RT_EVAL_ONB = 2, RT_EVAL_ONB_FAST = 3, RT_EVAL_OPTICS = 4, RT_EVAL_PERLIN = 5, RT_EVAL_TEXTURE = 6,
+    RT_EVAL_SAMPLERS = 7, RT_EVAL_BOUNCE = 8, RT_EVAL_BOUNCE_FAST = 9
+};
+int rt_debug_eval(rt_scene* scene, int kind, int32_t n, const float* h_in16, float* h_out16);
+
+/* ------------------------------------------------------------------ */
 /* Execution paths                                                      */
 /* ------------------------------------------------------------------ */
 /* The library holds an exact and a fast device implementation of world->hit() + color():

@@ -521,6 +521,16 @@ V3 lights_random(const rt_scene_desc *sc, V3 o, Rng &rng)
 // ---------------------------------------------------------------------------
 // color(), src/main.cpp:91-127, with the materials of src/material.h inlined
 // ---------------------------------------------------------------------------
+// orc_kat_bounce (test aid): when set, color() reports its first bounce here -- what was hit, the scattered ray and the
+// factor the recursion's result would be multiplied by -- and returns instead of following the scattered ray.  The
+// arithmetic of every branch is untouched; the probe only reads values the branch has computed.
+struct BounceProbe {
+    int hit = 0, material_kind = -1, scattered = 0;
+    float t = 0.0f;
+    V3 dir{0, 0, 0}, weight{0, 0, 0};
+};
+thread_local BounceProbe *tl_probe = nullptr;
+
 V3 color(const rt_scene_desc *sc, const Ray &r, int max_depth, int depth, Rng &rng)
 {
     ++tl_counters.rays;
@@ -531,6 +541,7 @@ V3 color(const rt_scene_desc *sc, const Ray &r, int max_depth, int depth, Rng &r
     }
     const rt_material &m = sc->materials[h.material];
     V3 emitted = m.kind == RT_MAT_DIFFUSE_LIGHT ? tex_value(sc, m.texture, h.u, h.v, h.p) : v3(0, 0, 0);
+    if (tl_probe) tl_probe->hit = 1, tl_probe->material_kind = m.kind, tl_probe->t = h.t, tl_probe->weight = emitted;
     if (!(depth < max_depth) || m.kind == RT_MAT_DIFFUSE_LIGHT) {
         if (m.kind == RT_MAT_DIFFUSE_LIGHT) ++tl_counters.end_light; else ++tl_counters.end_depth;
         return emitted;
@@ -551,6 +562,10 @@ V3 color(const rt_scene_desc *sc, const Ray &r, int max_depth, int depth, Rng &r
         float sc_cos = dot(h.n, dir); // lambertian::scattering_pdf, src/material.h:28-33
         if (sc_cos < 0.0f) sc_cos = 0.0f;
         float spdf = sc_cos / ORC_PI;
+        if (tl_probe) {
+            tl_probe->scattered = 1, tl_probe->dir = dir, tl_probe->weight = albedo * spdf / pdf_val;
+            return v3(0, 0, 0);
+        }
         return emitted + albedo * spdf * color(sc, scattered, max_depth, depth + 1, rng) / pdf_val;
     }
     case RT_MAT_METAL: { // src/material.h:65-78
@@ -559,6 +574,10 @@ V3 color(const rt_scene_desc *sc, const Ray &r, int max_depth, int depth, Rng &r
         V3 fuzz = (rng.mode == ORC_RNG_COUNTER && m.p0 == 0.0f) ? v3(0, 0, 0) : m.p0 * random_in_unit_sphere(rng);
         Ray spec{h.p, reflected + fuzz, r.time};
         V3 albedo = tex_value(sc, m.texture, h.u, h.v, h.p);
+        if (tl_probe) {
+            tl_probe->scattered = 1, tl_probe->dir = spec.d, tl_probe->weight = albedo;
+            return v3(0, 0, 0);
+        }
         return albedo * color(sc, spec, max_depth, depth + 1, rng);
     }
     case RT_MAT_DIELECTRIC: { // src/material.h:92-145
@@ -579,11 +598,19 @@ V3 color(const rt_scene_desc *sc, const Ray &r, int max_depth, int depth, Rng &r
         if (refract(r.d, outward_normal, ni_over_nt, refracted)) reflect_prob = schlick(cosine, ref_idx);
         else reflect_prob = 1.0f;
         Ray spec{h.p, rng.next() < reflect_prob ? reflected : refracted, r.time};
+        if (tl_probe) {
+            tl_probe->scattered = 1, tl_probe->dir = spec.d, tl_probe->weight = v3(1.0f, 1.0f, 1.0f);
+            return v3(0, 0, 0);
+        }
         return v3(1.0f, 1.0f, 1.0f) * color(sc, spec, max_depth, depth + 1, rng);
     }
     default: { // isotropic, src/material.h:187-196: time 0, flagged specular
         Ray spec{h.p, random_in_unit_sphere(rng), 0.0f};
         V3 albedo = tex_value(sc, m.texture, h.u, h.v, h.p);
+        if (tl_probe) {
+            tl_probe->scattered = 1, tl_probe->dir = spec.d, tl_probe->weight = albedo;
+            return v3(0, 0, 0);
+        }
         return albedo * color(sc, spec, max_depth, depth + 1, rng);
     }
     }
@@ -862,6 +889,37 @@ void orc_kat_texture(const rt_scene_desc *sc, int idx, float u, float v, const f
 {
     V3 c = tex_value(sc, idx, u, v, v3(p[0], p[1], p[2]));
     rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
+}
+
+// The samplers on the per-path stream (key, pixel), each from draw 0 -- the layout of rt_debug_eval's RT_EVAL_SAMPLERS:
+// out: lights_random(o)[3], random_cosine_direction[3], random_in_unit_sphere[3], random_in_unit_disk x y
+void orc_kat_samplers(const rt_scene_desc *sc, uint32_t key, uint32_t pixel, const float *o, float *out11)
+{
+    auto fresh = [&]() {
+        Rng r;
+        r.mode = ORC_RNG_COUNTER, r.key = key, r.pixel = pixel, r.n = 0;
+        return r;
+    };
+    Rng r0 = fresh(), r1 = fresh(), r2 = fresh(), r3 = fresh();
+    V3 a = lights_random(sc, v3(o[0], o[1], o[2]), r0), b = random_cosine_direction(r1), c = random_in_unit_sphere(r2), d = random_in_unit_disk(r3);
+    float v[11] = {a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, d.x, d.y};
+    memcpy(out11, v, sizeof v);
+}
+// world->hit() and ONE bounce of color() (src/main.cpp:91-127) at depth 0 of 50 on the stream (key, pixel) -- the layout of
+// RT_EVAL_BOUNCE: hit?, material kind, scattered?, direction[3], weight[3] (the factor the rest of the path is multiplied by;
+// the emitted radiance when the path ends here), t
+void orc_kat_bounce(const rt_scene_desc *sc, const float *ray7, uint32_t key, uint32_t pixel, float *out10)
+{
+    Rng rng;
+    rng.mode = ORC_RNG_COUNTER, rng.key = key, rng.pixel = pixel, rng.n = 0;
+    BounceProbe probe;
+    tl_probe = &probe;
+    Ray r{v3(ray7[0], ray7[1], ray7[2]), v3(ray7[3], ray7[4], ray7[5]), ray7[6]};
+    (void)color(sc, r, 50, 0, rng);
+    tl_probe = nullptr;
+    float v[10] = {(float)probe.hit, (float)probe.material_kind, (float)probe.scattered, probe.dir.x, probe.dir.y, probe.dir.z,
+                   probe.weight.x, probe.weight.y, probe.weight.z, probe.t};
+    memcpy(out10, v, sizeof v);
 }
 
 } // extern "C"

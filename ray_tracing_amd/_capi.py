@@ -19,6 +19,8 @@ RT_TRACE_NOALLOC_MAX_RAYS = 65536
 RT_OPT_RENDER_PATH, RT_OPT_TRACE_PATH = 1, 2
 (RT_OPT_BLOCK_KERNEL, RT_OPT_CHAIN_TASKS, RT_OPT_TARGET_TASKS, RT_OPT_PATHS_PER_LANE, RT_OPT_NODE_STEPS,
  RT_OPT_CHAIN_BLOCKS_PER_CU, RT_OPT_SHADE_BATCH, RT_OPT_LEAF_BATCH) = range(3, 11)
+(RT_EVAL_LIGHT_PDF, RT_EVAL_ONB, RT_EVAL_ONB_FAST, RT_EVAL_OPTICS, RT_EVAL_PERLIN, RT_EVAL_TEXTURE, RT_EVAL_SAMPLERS, RT_EVAL_BOUNCE,
+ RT_EVAL_BOUNCE_FAST) = range(1, 10)
 RT_CREATE_KEEP_BOX_RECORDS = 1
 RT_MULTI_REDUCE_ALWAYS = 1
 RT_PATH_AUTO, RT_PATH_EXACT, RT_PATH_FAST = 0, 1, 2
@@ -114,6 +116,7 @@ PROTOTYPES = {
     "rt_camera_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "rt_trace_rays_noalloc": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
+    "rt_debug_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p]),
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_int, []),
     "rt_device_count": (C.c_int, []),

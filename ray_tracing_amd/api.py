@@ -146,3 +146,12 @@ def trace_rays(scene, rays, t_min=0.001, t_max=3.4028234663852886e38, seed=0, no
     _check(fn(scene._s, rays.shape[0], rays.ctypes.data_as(C.c_void_p), C.c_float(t_min), C.c_float(t_max), seed,
               hits.ctypes.data_as(C.c_void_p)), name)
     return hits
+
+
+def debug_eval(scene, kind, items):
+    """rt_debug_eval: `items` is n x 16 float32 (unused columns 0); returns n x 16 float32."""
+    items = np.ascontiguousarray(items, dtype=np.float32).reshape(-1, 16)
+    out = np.zeros_like(items)
+    _check(_capi.load().rt_debug_eval(scene._s, kind, items.shape[0], items.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)),
+           "rt_debug_eval")
+    return out

@@ -969,6 +969,174 @@ __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n,
     out[i] = o;
 }
 
+// ---------------------------------------------------------------------------
+// rt_debug_eval: known-answer evaluation of the sampling / shading functions on the device (include/rt_amd.h).  Not on any
+// render path: one thread per item, 16 floats in, 16 floats out, the functions called exactly as the kernels call them,
+// both families (rt:: exact, rtf:: fast) side by side, so that a failing image test can be traced to the function.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ Rng eval_rng(const float *in, int at) { return Rng{__float_as_uint(in[at]), __float_as_uint(in[at + 1])}; }
+
+__global__ __launch_bounds__(256) void debug_eval_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf::Layout Y, int kind, int n,
+                                                         const float *__restrict__ in_all, float *__restrict__ out_all)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *in = in_all + 16 * (size_t)i;
+    float *out = out_all + 16 * (size_t)i;
+    float o16[16];
+    for (int k = 0; k < 16; ++k) o16[k] = 0.0f;
+    if (kind == RT_EVAL_LIGHT_PDF) {
+        // in: kind (0 xz_rect, 1 sphere), o, v, f[5], normal  out: rt::light_pdf_value, rt::cosine_pdf_value, the same two of rtf::
+        const bool rect = in[0] == 0.0f;
+        rt_prim pr{};
+        pr.kind = rect ? RT_PRIM_XZ_RECT : RT_PRIM_SPHERE;
+        for (int k = 0; k < 5; ++k) pr.f[k] = in[7 + k];
+        const V3 o = v3(in[1], in[2], in[3]), v = v3(in[4], in[5], in[6]), nrm = v3(in[12], in[13], in[14]);
+        o16[0] = light_pdf_value(pr, o, v);
+        Onb uvw;
+        uvw.build_from_w(nrm);
+        o16[1] = cosine_pdf_value(uvw, v);
+        rtf::SRec c{}; // the light record rt_records.cpp (emit_lights) writes for this primitive
+        for (int k = 0; k < 5; ++k) c.d[k] = __float_as_uint(pr.f[k]);
+        const float area = (pr.f[1] - pr.f[0]) * (pr.f[3] - pr.f[2]);
+        c.d[5] = __float_as_uint(area), c.d[6] = __float_as_uint(1.0f / area);
+        c.d[7] = rect ? RT_REC_LIGHT_RECT : RT_REC_LIGHT_SPHERE;
+        o16[2] = rtf::light_rec_pdf(c, o, rtf::funit(v));
+        o16[3] = rtf::cos_over_pi(rtf::funit(nrm), rtf::funit(v));
+    } else if (kind == RT_EVAL_ONB) {
+        // in: n  out: rt:: u v w, unit(n), sphere_uv(unit(n))   (the layout of the oracle's orc_kat_onb_uv)
+        const V3 nrm = v3(in[0], in[1], in[2]);
+        Onb b;
+        b.build_from_w(nrm);
+        const V3 p = unit(nrm);
+        float su, sv;
+        sphere_uv(p, su, sv);
+        const float v[14] = {b.u.x, b.u.y, b.u.z, b.v.x, b.v.y, b.v.z, b.w.x, b.w.y, b.w.z, p.x, p.y, p.z, su, sv};
+        for (int k = 0; k < 14; ++k) o16[k] = v[k];
+    } else if (kind == RT_EVAL_ONB_FAST) {
+        // in: n, a  out: rtf:: u v w, funit(n), local(a)
+        const V3 nrm = v3(in[0], in[1], in[2]);
+        rtf::Onb b;
+        b.build_from_w(nrm);
+        const V3 p = rtf::funit(nrm), l = b.local(v3(in[3], in[4], in[5]));
+        const float v[15] = {b.u.x, b.u.y, b.u.z, b.v.x, b.v.y, b.v.z, b.w.x, b.w.y, b.w.z, p.x, p.y, p.z, l.x, l.y, l.z};
+        for (int k = 0; k < 15; ++k) o16[k] = v[k];
+    } else if (kind == RT_EVAL_OPTICS) {
+        // in: v, n, ni_over_nt, cosine, ref_idx  out: reflect, ok, refracted, schlick   (orc_kat_optics)
+        const V3 a = v3(in[0], in[1], in[2]), nn = v3(in[3], in[4], in[5]);
+        const V3 rf = reflect(a, nn);
+        V3 rr = v3(0, 0, 0);
+        const bool ok = refract(a, nn, in[6], rr);
+        const float v[8] = {rf.x, rf.y, rf.z, ok ? 1.0f : 0.0f, ok ? rr.x : 0.0f, ok ? rr.y : 0.0f, ok ? rr.z : 0.0f, schlick(in[7], in[8])};
+        for (int k = 0; k < 8; ++k) o16[k] = v[k];
+    } else if (kind == RT_EVAL_PERLIN) {
+        // in: p  out: rt:: noise, turb; rtf:: noise, turb
+        const V3 p = v3(in[0], in[1], in[2]);
+        o16[0] = perlin_noise(S, p), o16[1] = perlin_turb(S, p);
+        o16[2] = rtf::fast_perlin_noise(p), o16[3] = rtf::fast_perlin_turb(p);
+    } else if (kind == RT_EVAL_TEXTURE) {
+        // in: texture index of the scene's table, u, v, p  out: rt::tex_value, rtf::fast_tex_value
+        const int idx = (int)in[0];
+        const V3 p = v3(in[3], in[4], in[5]);
+        const V3 a = tex_value(S, idx, in[1], in[2], p), b = rtf::fast_tex_value(S, idx, in[1], in[2], p);
+        o16[0] = a.x, o16[1] = a.y, o16[2] = a.z, o16[3] = b.x, o16[4] = b.y, o16[5] = b.z;
+    } else if (kind == RT_EVAL_SAMPLERS) {
+        // in: key, pixel (bit patterns), o  out: rt:: lights_random(o), random_cosine_direction, random_in_unit_sphere,
+        // random_in_unit_disk (x, y), each from the start of the stream (key, pixel); rtf:: rnd_unit_sphere, rnd_unit_disk (x, y)
+        const V3 o = v3(in[2], in[3], in[4]);
+        Rng r0 = eval_rng(in, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
+        const V3 a = lights_random(S, o, r0), b = random_cosine_direction(r1), c = random_in_unit_sphere(r2), d = random_in_unit_disk(r3);
+        const V3 e = rtf::rnd_unit_sphere(r4), f = rtf::rnd_unit_disk(r5);
+        const float v[16] = {a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, d.x, d.y, e.x, e.y, e.z, f.x, f.y};
+        for (int k = 0; k < 16; ++k) o16[k] = v[k];
+    }
+    for (int k = 0; k < 16; ++k) out[k] = o16[k];
+}
+
+// RT_EVAL_BOUNCE: world->hit() and ONE bounce of color() for the ray in[0..6] on the stream (key, pixel) = in[7], in[8].
+// out: hit (0/1), material kind, continues (0/1), scattered direction, throughput factor (T = 1 before the bounce; a path that
+// ends reports its radiance there), t.   EXACT family: the kernels of RT_PATH_EXACT.
+template <bool LANES>
+__global__ __launch_bounds__(256) void debug_bounce_exact_kernel(DevScene S, int n, const float *__restrict__ in_all, float *__restrict__ out_all)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool alive = i < n;
+    const float *in = in_all + 16 * (size_t)(alive ? i : 0);
+    Ray r{v3(in[0], in[1], in[2]), v3(in[3], in[4], in[5]), in[6]};
+    Rng rng = eval_rng(in, 7);
+    int *stack = LaneStacks<LANES>::get(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+    Hit h;
+    const bool any = closest_hit<LANES>(S, r, 0.001f, RT_FLT_MAX, alive, rng, h, stack);
+    if (!alive) return;
+    V3 T = v3(1, 1, 1), L = v3(0, 0, 0);
+    int depth = 0;
+    const int mat_kind = any ? S.materials[h.material].kind : -1;
+    const bool go = shade(S, any, h, r, T, depth, 50, rng, L);
+    float *out = out_all + 16 * (size_t)i;
+    const V3 w = go ? T : L;
+    const float v[16] = {any ? 1.0f : 0.0f, (float)mat_kind, go ? 1.0f : 0.0f, go ? r.d.x : 0.0f, go ? r.d.y : 0.0f, go ? r.d.z : 0.0f, w.x, w.y, w.z,
+                         any ? h.t : 0.0f, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 16; ++k) out[k] = v[k];
+}
+// the same on the record table (the scan, surface and shade of render_fast_kernel / render_fast_block_kernel)
+template <bool FLAT>
+__global__ __launch_bounds__(256) void debug_bounce_fast_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf::Layout Y, int n,
+                                                                const float *__restrict__ in_all, float *__restrict__ out_all)
+{
+    __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
+    rtf::stage_records(recs, lrecs, Y.n_stream, threadIdx.x, 256);
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool alive = i < n;
+    const float *in = in_all + 16 * (size_t)(alive ? i : 0);
+    rtf::Regs R;
+    load_records(recs, threadIdx.x & 63, R);
+    Ray r{v3(in[0], in[1], in[2]), v3(in[3], in[4], in[5]), in[6]};
+    Rng rng = eval_rng(in, 7);
+    float t;
+    int rec;
+    rtf::scan<FLAT>(recs, lrecs, Y, r, 0.001f, RT_FLT_MAX, alive, t, rec);
+    rtf::Surface sf;
+    rtf::build_surface(R, Y, r, t, rec, sf);
+    if (!alive) return;
+    V3 T = v3(1, 1, 1), L = v3(0, 0, 0);
+    int depth = 0;
+    const bool any = rec >= 0;
+    const bool go = rtf::shade<true>(S, recs, Y, any, sf, r, T, depth, 50, rng, L);
+    float *out = out_all + 16 * (size_t)i;
+    const V3 w = go ? T : L;
+    const float v[16] = {any ? 1.0f : 0.0f, any ? (float)sf.mat_kind : -1.0f, go ? 1.0f : 0.0f, go ? r.d.x : 0.0f, go ? r.d.y : 0.0f, go ? r.d.z : 0.0f,
+                         w.x, w.y, w.z, any ? t : 0.0f, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 16; ++k) out[k] = v[k];
+}
+// and on the library's own tree (the walk, surface and shade of render_fastlanes_kernel)
+__global__ __launch_bounds__(256) void debug_bounce_lanes_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf::Layout Y, int n,
+                                                                 int stack_levels, const float *__restrict__ in_all, float *__restrict__ out_all)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool alive = i < n;
+    const float *in = in_all + 16 * (size_t)(alive ? i : 0);
+    Ray r{v3(in[0], in[1], in[2]), v3(in[3], in[4], in[5]), in[6]};
+    Rng rng = eval_rng(in, 7);
+    extern __shared__ int bvh_stacks[]; // [4][stack_levels][64]
+    int *stack = &bvh_stacks[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * stack_levels * 64 + (threadIdx.x & 63)];
+    float t;
+    int prim;
+    const bool any = rtf::hit_bvh(S, r, 0.001f, RT_FLT_MAX, alive, rng, t, prim, stack);
+    if (!alive) return;
+    rtf::Surface sf;
+    sf.p = r.o, sf.n = v3(0, 0, 0), sf.u = sf.v = 0.0f, sf.face = prim, sf.mat_kind = 0u, sf.texture = -1, sf.p0 = 0.0f, sf.color = v3(0, 0, 0);
+    if (any) rtf::build_surface_lanes(S, r, t, prim, sf);
+    V3 T = v3(1, 1, 1), L = v3(0, 0, 0);
+    int depth = 0;
+    const bool go = rtf::shade<true>(S, recs, Y, any, sf, r, T, depth, 50, rng, L);
+    float *out = out_all + 16 * (size_t)i;
+    const V3 w = go ? T : L;
+    const float v[16] = {any ? 1.0f : 0.0f, any ? (float)sf.mat_kind : -1.0f, go ? 1.0f : 0.0f, go ? r.d.x : 0.0f, go ? r.d.y : 0.0f, go ? r.d.z : 0.0f,
+                         w.x, w.y, w.z, any ? t : 0.0f, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 16; ++k) out[k] = v[k];
+}
+
 } // namespace
 
 // ===========================================================================
@@ -1570,6 +1738,43 @@ extern "C" int rt_trace_rays_noalloc(rt_scene *s, int32_t n, const float *h_rays
     RT_HIP(hipMemcpy(d_rays, h_rays, 28 * N, hipMemcpyHostToDevice));
     RT_HIP(launch_trace(s, n, d_rays, t_min, t_max, seed, d_hits));
     RT_HIP(hipMemcpy(h_hits, d_hits, sizeof(rt_hit) * N, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_debug_eval(rt_scene *s, int kind, int32_t n, const float *h_in, float *h_out)
+{
+    if (!s || n < 0 || (n > 0 && (!h_in || !h_out))) return rt_fail(RT_ERR_INVALID, "rt_debug_eval: bad argument");
+    if (kind < RT_EVAL_LIGHT_PDF || kind > RT_EVAL_BOUNCE_FAST) return rt_fail(RT_ERR_INVALID, "rt_debug_eval: unknown kind %d", kind);
+    if (kind == RT_EVAL_BOUNCE_FAST && !s->fast_ok && !s->lanes_ok)
+        return rt_fail(RT_ERR_UNSUPPORTED, "rt_debug_eval: the fast path cannot run this scene (%s; and no ordered walk)", s->fast_why);
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(s->device));
+    const size_t bytes = sizeof(float) * 16 * (size_t)n;
+    float *d_in = nullptr, *d_out = nullptr;
+    RT_HIP(hipMalloc(&d_in, bytes));
+    hipError_t e = hipMalloc(&d_out, bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_in, h_in, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const dim3 g((n + 255) / 256), b(256);
+        if (kind == RT_EVAL_BOUNCE) {
+            if (s->dev.n_entries > RT_UNIFORM_WALK_MAX) hipLaunchKernelGGL(debug_bounce_exact_kernel<true>, g, b, 0, nullptr, s->dev, n, d_in, d_out);
+            else hipLaunchKernelGGL(debug_bounce_exact_kernel<false>, g, b, 0, nullptr, s->dev, n, d_in, d_out);
+        } else if (kind == RT_EVAL_BOUNCE_FAST) {
+            if (s->lanes_ok)
+                hipLaunchKernelGGL(debug_bounce_lanes_kernel, g, b, (size_t)4 * s->bvh_levels * 256, nullptr, s->dev, s->d_records, s->layout, n, s->bvh_levels, d_in, d_out);
+            else if (s->fast_flat)
+                hipLaunchKernelGGL(debug_bounce_fast_kernel<true>, g, b, 0, nullptr, s->dev, s->d_records, s->layout, n, d_in, d_out);
+            else
+                hipLaunchKernelGGL(debug_bounce_fast_kernel<false>, g, b, 0, nullptr, s->dev, s->d_records, s->layout, n, d_in, d_out);
+        } else {
+            hipLaunchKernelGGL(debug_eval_kernel, g, b, 0, nullptr, s->dev, s->d_records, s->layout, kind, n, d_in, d_out);
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return rt_fail(RT_ERR_NO_DEVICE, "rt_debug_eval: %s", hipGetErrorString(e));
     return RT_OK;
 }
 

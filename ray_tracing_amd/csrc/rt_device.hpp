@@ -801,6 +801,13 @@ RT_DEV V3 lights_random(const DevScene &S, V3 o, Rng &rng)
     return uvw.local(v3(x, y, z));
 }
 
+// cosine_pdf::value, src/pdf.h:13-24
+RT_DEV float cosine_pdf_value(const Onb &uvw, V3 dir)
+{
+    float cosine = dot(unit(dir), uvw.w);
+    return cosine > 0.0f ? cosine / RT_PI : 0.0f;
+}
+
 // camera::get_ray, src/camera.h:54-68
 RT_DEV Ray camera_ray(const rt_camera &c, float s, float t, V3 disk, float time01)
 {
@@ -848,8 +855,7 @@ RT_DEV bool shade(const DevScene &S, bool hit_any, const Hit &h, Ray &r, V3 &T, 
         V3 dir;
         if (rng.next() < 0.5f) dir = unit(lights_random(S, h.p, rng));
         else dir = unit(uvw.local(random_cosine_direction(rng)));
-        float cosine = dot(unit(dir), uvw.w);
-        float cos_val = cosine > 0.0f ? cosine / RT_PI : 0.0f;
+        float cos_val = cosine_pdf_value(uvw, dir);
         float pdf_val = 0.5f * lights_pdf_value(S, h.p, dir) + 0.5f * cos_val;
         float sc_cos = dot(h.n, dir);
         if (sc_cos < 0.0f) sc_cos = 0.0f;
@@ -869,7 +875,8 @@ RT_DEV bool shade(const DevScene &S, bool hit_any, const Hit &h, Ray &r, V3 &T, 
         if (m.p0 != 0.0f) fuzz = m.p0 * random_in_unit_sphere(rng);
         T = T * tex_value(S, m.texture, h.u, h.v, h.p);
         r = Ray{h.p, reflected + fuzz, r.time};
-        return true;
+        L = v3(0, 0, 0);
+        return !(T.x == 0.0f && T.y == 0.0f && T.z == 0.0f); // a zero weight is final (a black albedo)
     }
     if (m.kind == RT_MAT_DIELECTRIC) { // src/material.h:92-145
         V3 outward_normal;
@@ -894,7 +901,8 @@ RT_DEV bool shade(const DevScene &S, bool hit_any, const Hit &h, Ray &r, V3 &T, 
     V3 dir = random_in_unit_sphere(rng);
     T = T * tex_value(S, m.texture, h.u, h.v, h.p);
     r = Ray{h.p, dir, 0.0f};
-    return true;
+    L = v3(0, 0, 0);
+    return !(T.x == 0.0f && T.y == 0.0f && T.z == 0.0f); // black smoke (cornell_box_volumes): the path carries nothing further
 }
 
 } // namespace rt

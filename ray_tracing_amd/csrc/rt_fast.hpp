@@ -575,31 +575,33 @@ struct Onb {
 // hitable_list::pdf_value over the light records, src/hitable_list.h:67-77, for a direction of UNIT length (the only
 // caller has just normalised it: dot(v,v), its root and its reciprocal drop out of the reference's formulas)
 RTF_DEV bool within(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi) == x; } // lo <= x <= hi, false for NaN
+// one light record (rt_records.cpp: emit_lights) for a direction of unit length
+RTF_DEV float light_rec_pdf(const SRec &c, V3 o, V3 v)
+{
+    const uint32_t kind = c.d[7] & 15u;
+    float pdf = 0.0f;
+    if (kind == RT_REC_LIGHT_RECT) { // xz_rect::pdf_value, src/plane.h:76-91
+        const float iy = rcp(v.y);
+        const float t = (sf(c, 4) - o.y) * iy;
+        const float x = fmaf(t, v.x, o.x), z = fmaf(t, v.z, o.z);
+        const bool in = (t >= 0.0001f) & within(x, sf(c, 0), sf(c, 1)) & within(z, sf(c, 2), sf(c, 3));
+        pdf = in ? t * t * (fabsf(iy) * sf(c, 6)) : 0.0f; // t^2 / (|v.y| area): the record carries 1 / area beside the area
+    } else if (kind == RT_REC_LIGHT_SPHERE) { // sphere::pdf_value, src/sphere.h:68-83
+        const V3 oc = v3(o.x - sf(c, 0), o.y - sf(c, 1), o.z - sf(c, 2));
+        const float radius = sf(c, 3);
+        const float b = fdot(oc, v), occ = fdot(oc, oc);
+        const float disc = fmaf(b, b, fmaf(radius, radius, -occ));
+        const bool in = (disc > 0.0f) & (fsqrt(disc) - b > 0.001f); // the larger root decides (t1 <= t2)
+        const float cos_theta_max = fsqrt(1.0f - radius * radius * rcp(occ));
+        pdf = in ? rcp(2.0f * RT_PI * (1.0f - cos_theta_max)) : 0.0f;
+    }
+    return pdf;
+}
 RTF_DEV float lights_pdf_value(const uint32_t *__restrict__ recs, const Layout &Y, V3 o, V3 v)
 {
     const float weight = Y.inv_n_lights;
     float sum = 0.0f;
-    for (int k = 0; k < Y.n_lights; ++k) {
-        const SRec c = load_rec(recs, Y.lights_base + k);
-        const uint32_t kind = c.d[7] & 15u;
-        float pdf = 0.0f;
-        if (kind == RT_REC_LIGHT_RECT) { // xz_rect::pdf_value, src/plane.h:76-91
-            const float iy = rcp(v.y);
-            const float t = (sf(c, 4) - o.y) * iy;
-            const float x = fmaf(t, v.x, o.x), z = fmaf(t, v.z, o.z);
-            const bool in = (t >= 0.0001f) & within(x, sf(c, 0), sf(c, 1)) & within(z, sf(c, 2), sf(c, 3));
-            pdf = in ? t * t * (fabsf(iy) * sf(c, 6)) : 0.0f; // t^2 / (|v.y| area): the record carries 1 / area beside the area
-        } else if (kind == RT_REC_LIGHT_SPHERE) { // sphere::pdf_value, src/sphere.h:68-83
-            const V3 oc = v3(o.x - sf(c, 0), o.y - sf(c, 1), o.z - sf(c, 2));
-            const float radius = sf(c, 3);
-            const float b = fdot(oc, v), occ = fdot(oc, oc);
-            const float disc = fmaf(b, b, fmaf(radius, radius, -occ));
-            const bool in = (disc > 0.0f) & (fsqrt(disc) - b > 0.001f); // the larger root decides (t1 <= t2)
-            const float cos_theta_max = fsqrt(1.0f - radius * radius * rcp(occ));
-            pdf = in ? rcp(2.0f * RT_PI * (1.0f - cos_theta_max)) : 0.0f;
-        }
-        sum = fmaf(weight, pdf, sum);
-    }
+    for (int k = 0; k < Y.n_lights; ++k) sum = fmaf(weight, light_rec_pdf(load_rec(recs, Y.lights_base + k), o, v), sum);
     return sum;
 }
 // hitable_list::random, src/hitable_list.h:79-88, first half: the member is chosen per lane.  The (few) light
@@ -703,6 +705,7 @@ RTF_DEV V3 fast_tex_value(const DevScene &S, int idx, float u, float v, V3 p)
 // random_cosine_direction with its factor 2, src/vec3.h:179-180) are the same computation around different axes -- an
 // orthonormal basis, two draws, a point on a cap -- so those lanes run it together; a rect light (xz_rect::random,
 // src/plane.h:94-98, z takes the first draw) needs no basis.
+RTF_DEV float cos_over_pi(V3 wn, V3 dir) { return fmaxf(fdot(wn, dir), 0.0f) * (1.0f / RT_PI); } // both of unit length
 RTF_DEV void scatter_lambert(const uint32_t *__restrict__ recs, const Layout &Y, const Surface &h, V3 albedo, bool to_light,
                              const LightPick &lp, Rng &rng, V3 &nd, V3 &mul, bool &go)
 {
@@ -734,7 +737,7 @@ RTF_DEV void scatter_lambert(const uint32_t *__restrict__ recs, const Layout &Y,
     dir = funit(dir);
     // cosine_pdf::value (src/pdf.h:23-30) and lambertian::scattering_pdf (src/material.h:35-41) are the same number
     // once the normal has unit length: max(0, cos) / pi
-    const float sc = fmaxf(fdot(wn, dir), 0.0f) * (1.0f / RT_PI);
+    const float sc = cos_over_pi(wn, dir);
     const float pdf_val = 0.5f * lights_pdf_value(recs, Y, h.p, dir) + 0.5f * sc;
     const float wgt = sc * rcp(pdf_val);
     nd = dir;

@@ -52,6 +52,8 @@ def load():
         lib.orc_kat_perlin_turb.restype = C.c_float
         lib.orc_kat_perlin_turb.argtypes = [F]
         lib.orc_kat_texture.argtypes = [D, C.c_int, C.c_float, C.c_float, F, F]
+        lib.orc_kat_samplers.argtypes = [D, C.c_uint32, C.c_uint32, F, F]
+        lib.orc_kat_bounce.argtypes = [D, F, C.c_uint32, C.c_uint32, F]
         kat = np.load(os.path.join(GOLD, "kat.npz"))
         _perlin = np.ascontiguousarray(kat["perlin_gradients"], dtype=np.float32)
         lib.orc_set_perlin_table(_perlin.ctypes.data_as(C.c_void_p))
@@ -111,3 +113,21 @@ def counters(reset=False):
         lib.orc_counters_reset()
     names = ["rays", "slab_tests", "rect_tests", "sphere_tests", "scatters", "paths", "end_miss", "end_light", "end_depth"]
     return dict(zip(names, [int(x) for x in v]))
+
+
+def kat_samplers(host_scene, key, pixel, o):
+    """lights_random(o)[3], random_cosine_direction[3], random_in_unit_sphere[3], random_in_unit_disk x y: each from draw 0 of (key, pixel)."""
+    out = np.zeros(11, dtype=np.float32)
+    o = np.ascontiguousarray(o, dtype=np.float32)
+    F = C.POINTER(C.c_float)
+    load().orc_kat_samplers(host_scene.desc, int(key), int(pixel), o.ctypes.data_as(F), out.ctypes.data_as(F))
+    return out
+
+
+def kat_bounce(host_scene, ray7, key, pixel):
+    """world->hit() + one bounce of color(): hit?, material kind, scattered?, direction[3], weight[3], t."""
+    out = np.zeros(10, dtype=np.float32)
+    ray7 = np.ascontiguousarray(ray7, dtype=np.float32)
+    F = C.POINTER(C.c_float)
+    load().orc_kat_bounce(host_scene.desc, ray7.ctypes.data_as(F), int(key), int(pixel), out.ctypes.data_as(F))
+    return out

@@ -702,3 +702,23 @@ def test_sphere_field_1m_baseline_config_5():
     diff = np.abs(means["fast"][0] - means["exact"][0])
     se = np.sqrt(means["fast"][1] ** 2 + means["exact"][1] ** 2)
     assert np.all(diff <= 3.0 * se + 1e-5), (diff, se, means)
+
+
+@pytest.mark.parametrize("scene,nx,ny", [("random_spheres", 1200, 800), ("next_week_final", 800, 800)])
+def test_baseline_configs_1_and_3_at_their_full_image_size(scene, nx, ny):
+    """BASELINE.json configs[0] and configs[2] at their full image sizes (1200 x 800 book-1 spheres, 800 x 800 Next-Week final),
+    4 spp, through the path AUTO picks (the per-lane walk of the library's own tree): every pixel gets its samples, nothing is
+    NaN or negative, the two halves of the sample range add up to the whole, the image is not black, and its mean is that of
+    a small render of the same camera (a sixteenth of the pixels, more samples)."""
+    sc = Scene(HostScene(scene, nx / ny), 0)
+    spp = 4
+    full = gpu_render(sc, nx, ny, 0, spp, seed=2)
+    assert sc.info(_capi.RT_INFO_LAST_RENDER_PATH) == _capi.RT_PATH_FAST and sc.info(_capi.RT_INFO_RECORDS) == -1
+    assert full.shape == (ny, nx, 4) and np.all(full[..., 0] == spp) and np.isfinite(full).all() and (full[..., 1:] >= 0).all()
+    halves = gpu_render(sc, nx, ny, 0, 2, seed=2) + gpu_render(sc, nx, ny, 2, spp, seed=2)
+    assert np.allclose(full, halves, rtol=1e-4, atol=1e-4)
+    assert (full[..., 1:].sum(axis=-1) > 0).mean() > 0.2  # not black (the Next-Week room is lit by one small lamp: a third of the pixels at 4 spp)
+    small = gpu_render(sc, nx // 4, ny // 4, 0, 64, seed=9)
+    sc.close()
+    m_full, m_small = full[..., 1:].mean(axis=(0, 1)) / spp, small[..., 1:].mean(axis=(0, 1)) / 64
+    assert np.allclose(m_full, m_small, rtol=0.05), (m_full, m_small)
