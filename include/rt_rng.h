@@ -55,8 +55,8 @@ RT_RNG_FN uint32_t rt_mix32(uint32_t x)
  * one-bit difference then shifts the product by a constant, and neighbouring pixels' draws came out with a
  * correlation of -0.49.)
  * `w` is the path's pixel index, so a path's identity is the 64-bit pair (key, pixel) although the state a lane carries
- * from draw to draw is still one 32-bit counter (the pixel is recomputed from the tile and the lane's place in it
- * wherever draws are made: no register, no word in the kernels' path exchange).  The streams of a pixel are windows
+ * from draw to draw is one 32-bit counter beside the pixel word it carries anyway (rt_pixel_word: it is also where
+ * the path's radiance goes).  The streams of a pixel are windows
  * of that pixel's own 2^32-long sequence mix(c ^ pixel).
  * Round 2's stream was keyed by 32 bits in all and every stream was a window of ONE sequence: at the 2^37 paths of a
  * 3840 x 2160 x 16384 spp image every key value was shared by about 32 paths in different pixels.  Now paths of
@@ -70,9 +70,15 @@ RT_RNG_FN uint32_t rt_path_key(uint32_t seed, uint32_t sample)
     return rt_mix32(sample * 0xC2B2AE35U + seed * 0x27D4EB2FU + 1U);
 }
 
+/* The pixel word of a render: the row in the upper and the column in the lower 16 bits, row 0 at the top of the image
+ * (image sizes are at most 65536 x 65536).  A lane carries this ONE word as its path's place in the image -- the draws
+ * use it as it is, and the tile-local index and the address in the accumulator come out of it with a shift and a mask
+ * when the path ends -- where row * nx + column had to be recomputed at every place that draws. */
+RT_RNG_FN uint32_t rt_pixel_word(uint32_t row, uint32_t column) { return (row << 16) | column; }
+
 /* n-th draw of the path (key, pixel), uniform in [0,1) with 24 random bits.
- * pixel = row * nx + column with row 0 at the top of the image (the order of the output buffer); for the closest-hit
- * entry points (rt_trace_rays) it is the index of the ray in the batch and the key is rt_path_key(seed, 0). */
+ * pixel = rt_pixel_word(row, column) for a render; for the closest-hit entry points (rt_trace_rays) it is the index of
+ * the ray in the batch and the key is rt_path_key(seed, 0). */
 RT_RNG_FN float rt_draw(uint32_t key, uint32_t pixel, uint32_t n)
 {
     uint32_t x = rt_mix32_w(key + n * 0x9E3779B9U, pixel);

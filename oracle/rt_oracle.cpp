@@ -648,7 +648,7 @@ inline void shade_pixel(const rt_scene_desc *sc, int nx, int ny, int i, int j, i
     V3 col = v3(0, 0, 0);
     for (int s = 0; s < nss; ++s) {
         if (rng.mode == ORC_RNG_COUNTER) {
-            uint32_t pixel = (uint32_t)((ny - 1 - j) * nx + i);
+            uint32_t pixel = rt_pixel_word((uint32_t)(ny - 1 - j), (uint32_t)i);
             rng.key = rt_path_key(seed, (uint32_t)(sample * nss + s));
             rng.pixel = pixel, rng.n = 0;
         }

@@ -151,7 +151,7 @@ __device__ __forceinline__ void render_exact(DevScene S, RenderArgs A, float *__
                 const int sub = q - (q / A.sub_samples) * A.sub_samples;
                 const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3); // row 0 = image top
                 if (col < A.nx && row < A.ny) {
-                    rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), (uint32_t)(row * A.nx + col));
+                    rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), rt_pixel_word((uint32_t)row, (uint32_t)col));
                     // compute_one_sample_task::run, src/main.cpp:230-233; j counts rows from the bottom
                     const int j = A.ny - 1 - row;
                     const float u = float(col + rng.next()) / float(A.nx);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
                 const int sub = q - qs * A.sub_samples;
                 const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
                 if (col < A.nx && row < A.ny) {
-                    rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), (uint32_t)(row * A.nx + col));
+                    rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), rt_pixel_word((uint32_t)row, (uint32_t)col));
                     const int j = A.ny - 1 - row;
                     const float u = (float(col) + rng.next()) * inv_nx;
                     const float v = (float(j) + rng.next()) * inv_ny;
@@ -410,13 +410,14 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                                                                 RenderArgs A, float *__restrict__ accum, unsigned *__restrict__ next_task)
 {
     constexpr int NT = 64 * NW, TW = 4 * NW; // threads = pixels of the tile; tile width
+    static_assert((TW & (TW - 1)) == 0 && TW <= 32, "the tile-local index is cut out of the pixel word with masks");
     __shared__ float acc[3 * NT];
     __shared__ uint4 xch[3][NT]; // the path state in three 16-byte pieces, [piece][slot]
     __shared__ int4 cnt[NW];     // [wave].{x,y,z,w} = lanes of class 0..3
     __shared__ unsigned pool_next;
-    __shared__ int n_old[NW];    // [wave] live lanes that still belong to the previous task (CHAIN)
     __shared__ int task_now;     // the task the pool belongs to (CHAIN)
-    __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8];
+    __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8]; // the record table as rtf::stage_records lays it out: read by the scan (broadcast)
+                                                     // and, per lane, by the surface and light fetches
     // the camera is only needed by the refill: read from LDS there, it does not hold 24 SGPRs for the whole kernel
     // (the kernel is held to 80 SGPRs for eight waves per SIMD)
     __shared__ __align__(16) rt_camera lcam;
@@ -425,24 +426,19 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     int task = blockIdx.x; // CHAIN: the first one; the counter hands out gridDim.x, gridDim.x + 1, ...
     rtf::stage_records(recs, lrecs, Y.n_stream, tid, NT);
     if (tid < (int)(sizeof(rt_camera) / 4)) reinterpret_cast<uint32_t *>(&lcam)[tid] = reinterpret_cast<const uint32_t *>(&S.cam)[tid];
-    rtf::Regs R;
-    load_records(recs, lane, R);
 
     int tile_x, tile_y, s0, s1; // TW x 16 tiles
     unsigned total;
-    int old_tile_x = 0, old_tile_y = 0; // CHAIN: where the paths of the previous task belong
-    // The pixel word of the random stream (include/rt_rng.h: row * nx + column) is not carried from bounce to bounce -- the
-    // kernel has no register for it at eight waves per SIMD and the exchange no word -- but set again wherever draws are
-    // made, from the tile's first pixel (wave-uniform) and the lane's place in the tile.
-    uint32_t pix_base = 0u, old_pix_base = 0u;
-    auto pixel_word = [&](int px, int was_old) {
-        const uint32_t u = (uint32_t)px; // (24-bit multiply-add: full rate; nx <= 65536)
-        return (CHAIN && was_old ? old_pix_base : pix_base) + (__umul24(u / (uint32_t)TW, (uint32_t)A.nx) + u % (uint32_t)TW);
-    };
+    // A path's place in the image is ONE word, rt_pixel_word(row, column) (include/rt_rng.h): it keys the path's random
+    // stream, so it travels with the path (rng.w, a word of the exchange), and when the path ends it says where the
+    // radiance goes -- into the tile's sums in LDS if the pixel lies in the tile the block works on, else (CHAIN: a path
+    // of a tile that has gone to the image already) straight into the image.
+    uint32_t tile_word = 0u; // the pixel word of the tile's first pixel
+    constexpr uint32_t IN_TILE = (15u << 16) | (uint32_t)(TW - 1);
     auto open_task = [&](int tk) {
         const int tile = tk / A.n_chunks, chunk = tk - tile * A.n_chunks;
         tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
-        pix_base = (uint32_t)(tile_y * 16) * (uint32_t)A.nx + (uint32_t)(tile_x * TW);
+        tile_word = rt_pixel_word((uint32_t)(tile_y * 16), (uint32_t)(tile_x * TW));
         s0 = chunk * A.chunk_samples;
         s1 = min(s0 + A.chunk_samples, A.n_samples);
         total = tk < A.n_tasks ? (unsigned)NT * (unsigned)((s1 - s0) * A.sub_samples) : 0u;
@@ -473,9 +469,8 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), T = v3(1, 1, 1);
     float time = 0.0f;
     Rng rng{0u, 0u};
-    int depth = 0, pix = tid;
+    int depth = 0;
     int turn = 0;
-    int old = 0; // CHAIN: 1 = this lane's path belongs to the previous task
 #ifdef RT_COUNT_SHADE
     unsigned sc[16] = {0u};
 #endif
@@ -491,14 +486,14 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
                 const unsigned item = base + rank;
                 if (!alive && item < total) {
-                    pix = (int)(item % (unsigned)NT);
+                    const int pix = (int)(item % (unsigned)NT);
                     const int q = (int)(item / (unsigned)NT);
                     const int qs = A.sub_samples == 1 ? q : q / A.sub_samples;
                     const int sample = A.sample_begin + s0 + qs;
                     const int sub = q - qs * A.sub_samples;
                     const int col = tile_x * TW + (pix % TW), row = tile_y * 16 + (pix / TW);
                     if (col < A.nx && row < A.ny) {
-                        rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), (uint32_t)(row * A.nx + col));
+                        rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), rt_pixel_word((uint32_t)row, (uint32_t)col));
                         const int j = A.ny - 1 - row;
                         const float u = (float(col) + rng.next()) * inv_nx;
                         const float v = (float(j) + rng.next()) * inv_ny;
@@ -510,7 +505,6 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                         T = v3(1, 1, 1);
                         depth = 0;
                         alive = true;
-                        old = 0;
                     }
                 }
             }
@@ -525,37 +519,40 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         }
 #endif
         // ---- scan (waves without a live lane skip it) ---------------------------------------------------------------------
-        float t = 0.0f;
-        int rec = -1;
-        if (__any(alive)) rtf::scan<FLAT>(recs, lrecs, Y, Ray{o, d, time}, 0.001f, RT_FLT_MAX, alive, t, rec);
+        rtf::Best best = rtf::best_start(RT_FLT_MAX);
+        if (__any(alive)) best = rtf::scan_best<FLAT>(recs, lrecs, Y, Ray{o, d, time}, 0.001f, RT_FLT_MAX, alive);
 #ifdef RT_MEASURE_SCAN_TWICE // development (tools/build_variant.sh): the same scan again, to price the scan by difference
         if (__any(alive)) {
-            float t2;
-            int rec2;
-            rtf::scan<FLAT>(recs, lrecs, Y, Ray{o, d, time}, 0.0010001f, RT_FLT_MAX, alive, t2, rec2);
-            if (t2 < t) t = t2, rec = rec2;
+            const rtf::Best b2 = rtf::scan_best<FLAT>(recs, lrecs, Y, Ray{o, d, time}, 0.0010001f, RT_FLT_MAX, alive);
+            best = b2 < best ? b2 : best;
         }
 #endif
 
         // ---- what needs no company: the path ends (miss, lamp, depth limit) or gets its class -----------------------------
-        const int src = rec < 0 ? 0 : rec;
-        const uint32_t kw = rtf::sh_u(R.d[7], src); // cross-lane fetches: every lane takes part
-        const int m = Y.materials_base + (int)((kw >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK);
-        const uint32_t mat_kind = rtf::sh_u(R.d[0], m);
-        const V3 mcol = v3(rtf::sh_f(R.d[3], m), rtf::sh_f(R.d[4], m), rtf::sh_f(R.d[5], m));
+        // The low word of the best hit is the key of the record (rt_records.h): kind, flip, material and index without a fetch;
+        // the material record comes from the table in LDS, each lane reading its own.
+        const uint32_t key = rtf::best_key_of(best);
+        const bool hit = key != RT_REC_KEY_NONE;
+        const float t = rtf::best_t_of(best);
+        const int m = Y.materials_base + (hit ? (int)((key >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK) : 0);
+        const uint4 ma = *reinterpret_cast<const uint4 *>(lrecs + 8 * m);
+        const uint32_t mat_kind = ma.x;
         int cls = 3, to_light = 0, light = 0;
         V3 p = o;
         if (alive) {
-            if (rec < 0 || !(depth < A.max_depth) || mat_kind == RT_MAT_DIFFUSE_LIGHT) {
+            if (!hit || !(depth < A.max_depth) || mat_kind == RT_MAT_DIFFUSE_LIGHT) {
                 alive = false;
-                if (rec >= 0 && mat_kind == RT_MAT_DIFFUSE_LIGHT) { // radiance = T * emitted; de_nan, src/vec3.h:184-191
-                    const V3 L = v3(T.x * mcol.x, T.y * mcol.y, T.z * mcol.z);
-                    if (CHAIN && old) { // a path of the previous task: its tile has gone to the image already
-                        float *dst = accum + 4 * ((size_t)(old_tile_y * 16 + pix / TW) * A.nx + (old_tile_x * TW + pix % TW));
+                if (hit && mat_kind == RT_MAT_DIFFUSE_LIGHT) { // radiance = T * emitted; de_nan, src/vec3.h:184-191
+                    const uint2 mb = *reinterpret_cast<const uint2 *>(lrecs + 8 * m + 4);
+                    const V3 L = v3(T.x * __uint_as_float(ma.w), T.y * __uint_as_float(mb.x), T.z * __uint_as_float(mb.y));
+                    const uint32_t w = rng.w;
+                    if (CHAIN && ((w ^ tile_word) & ~IN_TILE) != 0u) { // a path of a tile that has gone to the image already
+                        float *dst = accum + 4 * ((size_t)(w >> 16) * A.nx + (w & 0xffffu));
                         if (L.x == L.x && L.x != 0.0f) atomicAdd(dst + 3, L.x * inv_sub);
                         if (L.y == L.y && L.y != 0.0f) atomicAdd(dst + 2, L.y * inv_sub);
                         if (L.z == L.z && L.z != 0.0f) atomicAdd(dst + 1, L.z * inv_sub);
                     } else {
+                        const int pix = (int)(((w >> 16) & 15u) * (uint32_t)TW + (w & (uint32_t)(TW - 1)));
                         if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
                         if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[NT + pix], L.y);
                         if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[2 * NT + pix], L.z);
@@ -567,7 +564,6 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
                 cls = 0;
                 if (mat_kind == RT_MAT_LAMBERTIAN) {
                     cls = 2;
-                    rng.w = pixel_word(pix, old);
                     to_light = rng.next() < 0.5f ? 1 : 0;
                     if (to_light) {
                         light = rtf::lights_index(Y, rng);
@@ -582,10 +578,6 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         const unsigned long long mine = cls == 0 ? b0 : cls == 1 ? b1 : cls == 2 ? b2 : ~(b0 | b1 | b2);
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
         if (lane == 0) cnt[wave] = make_int4(__popcll(b0), __popcll(b1), __popcll(b2), 64 - __popcll(b0 | b1 | b2));
-        if (CHAIN) {
-            const int n = __popcll(__ballot(cls != 3 && old != 0));
-            if (lane == 0) n_old[wave] = n;
-        }
         __syncthreads();
         // Slots: the specular lanes first, then as many of the dead lanes as it takes to fill their last wave, then the
         // diffuse lanes (rect light, then axis sampling), then the other dead lanes.  The padding keeps specular and diffuse
@@ -607,15 +599,12 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         const int g = low + rank;
         const int dst = cls == 0 ? g : cls == 1 ? tot0 + pad + g : cls == 2 ? tot0 + pad + tot1 + g : g < pad ? tot0 + g : tot0 + tot1 + tot2 + g;
         // (the ray's time is not carried: nothing the record table can hold -- static spheres and rects -- reads it)
-        const uint32_t packed = (uint32_t)depth | ((uint32_t)pix << 16) | ((uint32_t)cls << 25) | ((uint32_t)to_light << 27) | ((uint32_t)light << 28);
+        // the record that was hit travels as its index and whether it is a box (where its key lies in the LDS copy)
+        const uint32_t rec_bits = hit ? (RT_KEY_INDEX(key) | ((key & 15u) == RT_REC_BOX ? 64u : 0u)) : 0u;
+        const uint32_t packed = (uint32_t)depth | ((uint32_t)cls << 16) | ((uint32_t)to_light << 18) | ((uint32_t)light << 19) | (rec_bits << 23);
         xch[0][dst] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(d.x));
         xch[1][dst] = make_uint4(__float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(T.x), __float_as_uint(T.y));
-        xch[2][dst] = make_uint4(__float_as_uint(T.z), rng.x, packed, (uint32_t)src | ((uint32_t)old << 8));
-        int old_alive = 0;
-        if (CHAIN) {
-#pragma unroll
-            for (int w2 = 0; w2 < NW; ++w2) old_alive += n_old[w2];
-        }
+        xch[2][dst] = make_uint4(__float_as_uint(T.z), rng.x, packed, rng.w);
         __syncthreads();
         if (!CHAIN && n_dead == NT && pool_now >= total) break; // the same for every wave of the block
         // The slots are sorted by class, so read in place wave 0 would always get the costliest paths and the last wave the
@@ -627,23 +616,22 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         p = v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
         d = v3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
         T = v3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
-        rng.x = q2.y;
+        rng.x = q2.y, rng.w = q2.w;
         const uint32_t word = q2.z;
-        const int hit_rec = (int)(q2.w & 255u);
-        old = (int)((q2.w >> 8) & 1u);
-        depth = (int)(word & 0xffffu), pix = (int)((word >> 16) & 511u), cls = (int)((word >> 25) & 3u);
-        to_light = (int)((word >> 27) & 1u), light = (int)(word >> 28);
+        depth = (int)(word & 0xffffu), cls = (int)((word >> 16) & 3u);
+        to_light = (int)((word >> 18) & 1u), light = (int)((word >> 19) & 15u);
+        const int hit_rec = (int)((word >> 23) & 63u);
+        const bool hit_box = ((word >> 29) & 1u) != 0u;
         alive = cls != 3;
         o = p;
         if (CHAIN && pool_now >= total) { // the pool is empty (the same finding in every wave of the block)
             if (task >= A.n_tasks) { // nothing left to take
                 if (n_dead == NT) break;
-            } else if (old_alive == 0) {
-                // the tile goes to the image, the paths still on their way become the previous task's, the next task opens
+            } else {
+                // the tile goes to the image and the next task opens; the paths still on their way find, when they end, that
+                // their pixel is not in the block's tile any more and add to the image themselves
                 flush(true); // (every thread reads and clears the sums of its own pixel only: no barrier in between)
                 acc[tid] = 0.0f, acc[NT + tid] = 0.0f, acc[2 * NT + tid] = 0.0f;
-                old_tile_x = tile_x, old_tile_y = tile_y, old_pix_base = pix_base;
-                old = alive ? 1 : 0;
                 if (tid == 0) {
                     task_now = (int)(atomicAdd(next_task, 1u) + gridDim.x);
                     pool_next = 0u;
@@ -657,22 +645,13 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
         // ---- shade: the lanes of a wave now mostly share a class -------------------------------------------------------------
         if (__any(alive)) {
             rtf::Surface sf;
-            {   // rtf::build_surface with the point already known; cross-lane fetches by every lane
-                const uint32_t kw2 = rtf::sh_u(R.d[7], hit_rec);
-                const float f0 = rtf::sh_f(R.d[0], hit_rec), f1 = rtf::sh_f(R.d[1], hit_rec), f2 = rtf::sh_f(R.d[2], hit_rec);
-                const float f4 = rtf::sh_f(R.d[4], hit_rec), f5 = rtf::sh_f(R.d[5], hit_rec), f6 = rtf::sh_f(R.d[6], hit_rec);
-                sf.p = p, sf.u = sf.v = 0.0f;
-                sf.n = rtf::record_normal(R, kw2, hit_rec, p, f0, f1, f2, f4, f5, f6, sf.face);
-                const int m2 = Y.materials_base + (int)((kw2 >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK);
-                sf.mat_kind = rtf::sh_u(R.d[0], m2);
-                sf.texture = -1;
-                sf.p0 = rtf::sh_f(R.d[2], m2);
-                sf.color = v3(rtf::sh_f(R.d[3], m2), rtf::sh_f(R.d[4], m2), rtf::sh_f(R.d[5], m2));
+            {   // the record this lane's path hit: its key lies in dword 3 (box) or 4 of the LDS copy
+                const uint32_t *r = lrecs + 8 * hit_rec;
+                rtf::build_surface_lds(lrecs, Y, alive ? (hit_box ? r[3] : r[4]) : (uint32_t)RT_REC_RECT, p, sf); // (a dead lane: any valid key)
             }
             V3 nd = d, mul = sf.color;
             float ntime = time;
             bool go = alive;
-            rng.w = pixel_word(pix, old); // the path this lane took over in the exchange
 #ifdef RT_COUNT_SHADE
             {
                 const int n0 = __popcll(__ballot(alive & (cls == 0))), n1 = __popcll(__ballot(alive & (cls == 1))), n2 = __popcll(__ballot(alive & (cls == 2)));
@@ -804,10 +783,15 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     if (task >= A.n_tasks) return;
 
     int tile_x, tile_y, s0, s1, total;
-    // (A.chain: the lanes of paths that belong to the previous task carry their pixel's index in the image, with the sign bit)
+    // A path's place in the image is its pixel word (rng.w = rt_pixel_word(row, column), include/rt_rng.h): it keys the
+    // random stream, and when the path ends it says where the radiance goes -- the tile's sums in LDS if the pixel lies in
+    // the tile the wave works on, else (A.chain: a path of a tile that has gone to the image already) the image itself.
+    uint32_t tile_word = 0u;
+    constexpr uint32_t IN_TILE = (7u << 16) | 7u;
     auto open_task = [&](int tk) {
         const int tile = tk / A.n_chunks, chunk = tk - tile * A.n_chunks;
         tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
+        tile_word = rt_pixel_word((uint32_t)(tile_y * 8), (uint32_t)(tile_x * 8));
         s0 = chunk * A.chunk_samples;
         s1 = min(s0 + A.chunk_samples, A.n_samples);
         total = tk < A.n_tasks ? 64 * (s1 - s0) * A.sub_samples : 0;
@@ -824,12 +808,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
     V3 T = v3(1, 1, 1);
     Rng rng{0u, 0u};
-    int depth = 0, pix = lane;
-    // the pixel word of the random stream (include/rt_rng.h), set again wherever draws are made instead of held in a register
-    auto pixel_word = [&](int px) {
-        const uint32_t u = (uint32_t)px;
-        return px < 0 ? u & 0x7fffffffu : (uint32_t)(tile_y * 8 * A.nx + tile_x * 8) + (__umul24(u >> 3, (uint32_t)A.nx) + (u & 7u));
-    };
+    int depth = 0;
     rtf::Walk w;
     rtf::walk_start(w, r, RT_FLT_MAX, false);
 #ifdef RT_COUNT_WALK
@@ -846,15 +825,16 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
             RT_COUNT(7, waiting);
             if (waiting) {
                 const bool hit_any = w.best_prim >= 0;
-                rng.w = pixel_word(pix);
                 rtf::Surface sf;
                 sf.p = r.o; // a miss ends the path; shade still writes the (dead) ray from it
                 if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
                 V3 L;
                 if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
                     alive = false;
-                    if (pix < 0) { // a path of the previous task: its tile has gone to the image already
-                        float *dst = accum + 4 * (size_t)(pix & 0x7fffffff);
+                    const uint32_t pw = rng.w;
+                    const int pix = (int)(((pw >> 16) & 7u) * 8u + (pw & 7u));
+                    if (A.chain && ((pw ^ tile_word) & ~IN_TILE) != 0u) { // a path of a tile that has gone to the image already
+                        float *dst = accum + 4 * ((size_t)(pw >> 16) * A.nx + (pw & 0xffffu));
                         const float inv_sub = 1.0f / (float)A.sub_samples;
                         if (L.x == L.x && L.x != 0.0f) atomicAdd(dst + 3, L.x * inv_sub);
                         if (L.y == L.y && L.y != 0.0f) atomicAdd(dst + 2, L.y * inv_sub);
@@ -867,13 +847,12 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                 }
             }
             bool fresh = waiting & alive; // scattered: the new ray is in r
-            // The pool is empty: the tile goes to the image, the paths still on their way become the previous task's (they
-            // add to the image themselves), and the wave takes the next task, so its free lanes refill at once instead of
-            // idling until the longest of the last paths ends.  (Not while paths of the task before are still alive.)
-            if (A.chain && next >= total && task < A.n_tasks && !__any(alive & (pix < 0))) {
+            // The pool is empty: the tile goes to the image and the wave takes the next task, so its free lanes refill at once
+            // instead of idling until the longest of the last paths ends; the paths still on their way find, when they end,
+            // that their pixel is not in the wave's tile any more and add to the image themselves.
+            if (A.chain && next >= total && task < A.n_tasks) {
                 flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
                 acc[lane] = 0.0f, acc[64 + lane] = 0.0f, acc[128 + lane] = 0.0f;
-                if (alive) pix = (int)(0x80000000u | (uint32_t)((tile_y * 8 + (pix >> 3)) * A.nx + tile_x * 8 + (pix & 7)));
                 unsigned nt = 0u;
                 if (lane == 0) nt = atomicAdd(next_task, 1u);
                 task = (int)(__builtin_amdgcn_readfirstlane(nt) + gridDim.x * WAVES_PER_BLOCK);
@@ -885,14 +864,14 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
                 const int item = next + rank;
                 if (!alive && item < total) {
-                    pix = item & 63;
+                    const int pix = item & 63;
                     const int q = item >> 6;
                     const int qs = A.sub_samples == 1 ? q : q / A.sub_samples;
                     const int sample = A.sample_begin + s0 + qs;
                     const int sub = q - qs * A.sub_samples;
                     const int col = tile_x * 8 + (pix & 7), row = tile_y * 8 + (pix >> 3);
                     if (col < A.nx && row < A.ny) {
-                        rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), (uint32_t)(row * A.nx + col));
+                        rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), rt_pixel_word((uint32_t)row, (uint32_t)col));
                         const int j = A.ny - 1 - row;
                         const float u = (float(col) + rng.next()) * inv_nx;
                         const float v = (float(j) + rng.next()) * inv_ny;
@@ -927,8 +906,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
         if (__popcll(__ballot(at_leaf)) >= A.leaf_batch || !__any(w.cur >= 0)) {
             RT_COUNT(1, at_leaf);
             RT_COUNT_WAVE(5, __any(at_leaf));
-            if (at_leaf) {
-                rng.w = pixel_word(pix); // a constant_medium draws (src/volume.h:43)
+            if (at_leaf) { // (a constant_medium draws, src/volume.h:43)
                 rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
             }
         }

@@ -182,7 +182,8 @@ typedef unsigned long long Best;
 RTF_DEV Best best_start(float t_max) { return ((Best)__float_as_uint(t_max) << 32) | RT_REC_KEY_NONE; }
 RTF_DEV Best best_of(float t, uint32_t key) { return ((Best)__float_as_uint(t) << 32) | key; }
 RTF_DEV float best_t_of(Best b) { return __uint_as_float((uint32_t)(b >> 32)); }
-RTF_DEV int best_rec_of(Best b) { return (uint32_t)b == RT_REC_KEY_NONE ? -1 : (int)((uint32_t)b & 255u); }
+RTF_DEV int best_rec_of(Best b) { return (uint32_t)b == RT_REC_KEY_NONE ? -1 : (int)RT_KEY_INDEX((uint32_t)b); }
+RTF_DEV uint32_t best_key_of(Best b) { return (uint32_t)b; } // RT_REC_KEY of the record that was hit, RT_REC_KEY_NONE on a miss
 
 // One rect record against the ray of its chain, and the update of the lane's best hit.
 // What the compiler makes of rect_in() is 6 v_cmp + 5 s_and_b64 + 2 v_cndmask; the SIMD issues one scalar instruction
@@ -220,8 +221,10 @@ RTF_DEV void rect_update_v(float k, uint32_t key, float a0, float a1, float b0, 
 // `count` rect records of one chain and axis from record `index` on: nothing to decode, the loop is fetch + test.
 // The records come from the block's copy of the table in LDS with broadcast reads (every lane the same address): the
 // LDS pipe is idle otherwise, the scalar pipe was the busy one, and the next record's read is in flight during the test.
-// In that copy (stage_records) a stream record carries its key: a rect in dword 4 (the plane moves to dword 5), a sphere
-// in dword 4, a box in dword 3.
+// In that copy (stage_records) a stream record carries its key and, beside what the scan reads, what shading reads:
+//   rect    d0-3 a0 a1 b0 b1 | d4 key, d5 the plane | d6 d7 world normal x, z
+//   sphere  d0-2 centre, d3 radius | d4 key, d5 1 / radius
+//   box     d0-2 p0, d3 key | d4-6 p1          (its second record, BOX_AUX, as in memory)
 struct LRec {
     uint4 a;   // a0 a1 b0 b1 (rect) | cx cy cz r (sphere)
     uint2 kk;  // key; rect: the plane
@@ -233,7 +236,7 @@ RTF_DEV LRec lds_rec(const uint32_t *lrecs, int i)
     r.kk = *reinterpret_cast<const uint2 *>(lrecs + 8 * i + 4);
     return r;
 }
-// the block's copy of the record table (all RT_REC_MAX + 1 records), with the keys of the stream records put in;
+// the block's copy of the record table (all RT_REC_MAX + 1 records), stream records re-arranged as above;
 // every thread of the block calls it, the caller's barrier follows
 RTF_DEV void stage_records(const uint32_t *__restrict__ recs, uint32_t *lrecs, int n_stream, int tid, int n_threads)
 {
@@ -243,8 +246,8 @@ RTF_DEV void stage_records(const uint32_t *__restrict__ recs, uint32_t *lrecs, i
         if (i < n_stream) {
             const uint32_t kw = recs[8 * i + 7], kind = kw & 15u;
             const uint32_t key = RT_REC_KEY(kw, i);
-            if (kind == RT_REC_RECT) v = j == 4 ? key : j == 5 ? recs[8 * i + 4] : v;
-            if (kind == RT_REC_SPHERE) v = j == 4 ? key : v;
+            if (kind == RT_REC_RECT) v = j == 4 ? key : j >= 5 ? recs[8 * i + j - 1] : v;
+            if (kind == RT_REC_SPHERE) v = j == 4 ? key : j == 5 ? recs[8 * i + 4] : v;
             if (kind == RT_REC_BOX) v = j == 3 ? key : v;
         }
         lrecs[k] = v;
@@ -348,8 +351,7 @@ RTF_DEV void sphere_roots(V3 o, V3 d, float dd, float inv_dd, float cx, float cy
 // The scan of a flat stream stored in runs (rt_records.h): per chain three loops of rects (one per axis) and one of
 // boxes, then the spheres; run lengths come from the kernel arguments, so a record costs its fetch, its test and the loop's counter.
 // `lrecs`: the record stream in LDS; `recs`: the table in memory (instance chains, read with scalar loads).
-RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min,
-                       float t_max, bool alive, float &best_t, int &best_rec)
+RTF_DEV Best scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min, float t_max)
 {
     Best best = best_start(t_max);
     LocalRay l;
@@ -390,20 +392,20 @@ RTF_DEV void scan_runs(const uint32_t *__restrict__ recs, const uint32_t *lrecs,
                      : [t] "v"(t), [cand] "v"(cand), [disc] "v"(disc), [tmin] "s"(t_min), [tmax] "s"(t_max)
                      : "vcc");
     }
-    best_t = best_t_of(best);
-    best_rec = alive ? best_rec_of(best) : -1;
+    return best;
 }
 
+// the lane's best hit as one number (best_t_of, best_rec_of, best_key_of); a lane that is not alive reports a miss
 template <bool FLAT>
-RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min, float t_max,
-                  bool alive, float &best_t, int &best_rec)
+RTF_DEV Best scan_best(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min, float t_max,
+                       bool alive)
 {
     if (FLAT) { // the stream is stored in runs (the host only asks for FLAT when it is)
-        scan_runs(recs, lrecs, Y, wr, t_min, t_max, alive, best_t, best_rec);
-        return;
+        const Best b = scan_runs(recs, lrecs, Y, wr, t_min, t_max);
+        return alive ? b : best_start(t_max);
     }
     Best best = best_start(t_max);
-    best_t = t_max; // the bound the tests below compare with: always the t of `best`
+    float best_t = t_max; // the bound the tests below compare with: always the t of `best`
     int resume = 0;
     uint32_t cur_chain = 0;
     LocalRay w, l; // world ray, ray of the current chain
@@ -472,7 +474,14 @@ RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, cons
         best = take ? cand : best;
         best_t = take ? t : best_t;
     }
-    best_rec = best_rec_of(best);
+    return best;
+}
+template <bool FLAT>
+RTF_DEV void scan(const uint32_t *__restrict__ recs, const uint32_t *lrecs, const Layout &Y, const Ray &wr, float t_min, float t_max,
+                  bool alive, float &best_t, int &best_rec)
+{
+    const Best b = scan_best<FLAT>(recs, lrecs, Y, wr, t_min, t_max, alive);
+    best_t = best_t_of(b), best_rec = best_rec_of(b);
 }
 
 // what shading needs about the hit, built after the scan from the winning record
@@ -514,6 +523,45 @@ RTF_DEV V3 record_normal(const Regs &R, uint32_t kw, int rec, V3 p, float f0, fl
     const bool xz = ((kw >> RT_KW_AXIS_SHIFT) & 3u) == 1u;
     const V3 nr = v3(f5, xz ? ((kw & RT_KW_FLIP) ? -1.0f : 1.0f) : 0.0f, f6);
     return kind == RT_REC_SPHERE ? ns : kind == RT_REC_BOX ? nb : nr;
+}
+// The same from the block's copy of the table in LDS (stage_records' layout), every lane for itself: the two halves of
+// the record it hit (`key`: the low word of its best hit) and of its material record, four 16-byte reads where
+// build_surface makes a dozen cross-lane fetches.  `p` is the hit point.
+RTF_DEV void build_surface_lds(const uint32_t *lrecs, const Layout &Y, uint32_t key, V3 p, Surface &s)
+{
+    const int rec = (int)RT_KEY_INDEX(key);
+    const uint32_t kind = key & 15u;
+    const uint4 ra = *reinterpret_cast<const uint4 *>(lrecs + 8 * rec), rb = *reinterpret_cast<const uint4 *>(lrecs + 8 * rec + 4);
+    const int m = Y.materials_base + (int)((key >> RT_KW_MAT_SHIFT) & RT_KW_MAT_MASK);
+    const uint4 ma = *reinterpret_cast<const uint4 *>(lrecs + 8 * m);
+    const uint2 mb = *reinterpret_cast<const uint2 *>(lrecs + 8 * m + 4);
+    s.p = p, s.u = s.v = 0.0f, s.face = 0;
+    const bool flip = (key & RT_KW_FLIP) != 0;
+    V3 n;
+    if (kind == RT_REC_SPHERE) { // (p - c) / r, src/sphere.h:41, then flip_normals
+        const float k = flip ? -__uint_as_float(rb.y) : __uint_as_float(rb.y);
+        n = v3((p.x - __uint_as_float(ra.x)) * k, (p.y - __uint_as_float(ra.y)) * k, (p.z - __uint_as_float(ra.z)) * k);
+    } else if (kind == RT_REC_BOX) { // box_normal with the second record read from LDS
+        const uint4 xa = *reinterpret_cast<const uint4 *>(lrecs + 8 * (rec + 1));
+        const float az = __uint_as_float(lrecs[8 * (rec + 1) + 4]), ax = __uint_as_float(xa.w);
+        const V3 lo = v3(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z));
+        const V3 hi = v3(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z));
+        const V3 q = v3(p.x - __uint_as_float(xa.x), p.y - __uint_as_float(xa.y), p.z - __uint_as_float(xa.z));
+        const float qx = fmaf(q.x, ax, q.z * az), qy = q.y, qz = fmaf(q.z, ax, -(q.x * az));
+        const float ex = fabsf(qx) - 0.5f * (hi.x - lo.x), ey = fabsf(qy) - 0.5f * (hi.y - lo.y), ez = fabsf(qz) - 0.5f * (hi.z - lo.z);
+        const bool is_x = (ex >= ey) & (ex >= ez), is_y = !is_x & (ey >= ez);
+        const float sx = qx < 0.0f ? -1.0f : 1.0f, sy = qy < 0.0f ? -1.0f : 1.0f, sz = qz < 0.0f ? -1.0f : 1.0f;
+        s.face = is_x ? (qx < 0.0f ? 0 : 1) : is_y ? (qy < 0.0f ? 2 : 3) : (qz < 0.0f ? 4 : 5);
+        n = is_x ? v3(sx * ax, 0.0f, sx * az) : is_y ? v3(0.0f, sy, 0.0f) : v3(-sz * az, 0.0f, sz * ax);
+    } else { // a rect: its world normal (y is +-1 for an xz rect, 0 otherwise)
+        const bool xz = ((key >> RT_KW_AXIS_SHIFT) & 3u) == 1u;
+        n = v3(__uint_as_float(rb.z), xz ? (flip ? -1.0f : 1.0f) : 0.0f, __uint_as_float(rb.w));
+    }
+    s.n = n;
+    s.mat_kind = ma.x;
+    s.texture = (int32_t)ma.y;
+    s.p0 = __uint_as_float(ma.z);
+    s.color = v3(__uint_as_float(ma.w), __uint_as_float(mb.x), __uint_as_float(mb.y));
 }
 RTF_DEV void build_surface(const Regs &R, const Layout &Y, const Ray &wr, float t, int rec, Surface &s)
 {

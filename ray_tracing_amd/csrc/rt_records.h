@@ -59,9 +59,14 @@ enum rt_rec_kind {
 #define RT_KW_RANK_SHIFT 26   /* 6 bits */
 #define RT_KW_RANK_MASK 0x3fu
 /* The scan's per-lane best hit is ONE 64-bit number, smaller = better: t's bits (t > 0, so they order like t) above a key
- * of the record, (63 - rank) << 8 | stream index.  A hit replaces the best iff its number is smaller: nearer, or as near
- * and met later by the reference's walk. */
-#define RT_REC_KEY(kw, index) ((((RT_KW_RANK_MASK - (((kw) >> RT_KW_RANK_SHIFT) & RT_KW_RANK_MASK))) << 8) | (uint32_t)(index))
+ * of the record.  The key is the record's kind word re-arranged: 63 - rank in the top six bits (so that, of two hits at
+ * exactly the same t, the one the reference's walk meets later is the smaller number), the material, and the stream
+ * index in place of the chain bits; kind, axis and flip stay where they are.  A hit replaces the best iff its number is
+ * smaller, and afterwards the low word of the best IS what shading needs to know about the record: no fetch. */
+#define RT_REC_KEY(kw, index) (((RT_KW_RANK_MASK - (((kw) >> RT_KW_RANK_SHIFT) & RT_KW_RANK_MASK)) << RT_KW_RANK_SHIFT) | \
+                               ((kw) & ((RT_KW_MAT_MASK << RT_KW_MAT_SHIFT) | 0x1ffu)) | ((uint32_t)(index) << RT_KEY_INDEX_SHIFT))
+#define RT_KEY_INDEX_SHIFT 9
+#define RT_KEY_INDEX(key) (((key) >> RT_KEY_INDEX_SHIFT) & 63u)
 #define RT_REC_KEY_NONE 0xffffffffu
 
 typedef struct rt_record_table {
