@@ -356,7 +356,10 @@ enum rt_option {
     RT_OPT_NODE_STEPS = 7,          /* per-lane walk: node steps between two looks at who waits (2 or 4) */
     RT_OPT_CHAIN_BLOCKS_PER_CU = 8, /* per-lane walk: blocks per CU of the chained grid */
     RT_OPT_SHADE_BATCH = 9,         /* per-lane walk: lanes whose walk is over wait until this many of a wave's 64 are */
-    RT_OPT_LEAF_BATCH = 10          /* per-lane walk: lanes standing on a leaf wait until this many do */
+    RT_OPT_LEAF_BATCH = 10,         /* per-lane walk: lanes standing on a leaf wait until this many do */
+    RT_OPT_LANES_REGROUP = 11,      /* per-lane walk, trees of fewer than 32767 nodes and leaves: 1 = the block kernel that regroups its
+                                       paths every few node steps, 0 = the wave kernel (default: the library's choice) */
+    RT_OPT_REGROUP_ROUNDS = 12      /* that kernel: rounds of (two node steps + one leaf test) between two regroups */
 };
 enum rt_path { RT_PATH_AUTO = 0, RT_PATH_EXACT = 1, RT_PATH_FAST = 2 };
 int rt_scene_set_option(rt_scene* scene, int option, int value);

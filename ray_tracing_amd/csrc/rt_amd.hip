@@ -59,6 +59,7 @@ struct RenderArgs {
     int32_t chain;         // per-lane fast path: 1 = a wave takes further tasks from the counter when its pool is empty
     int32_t shade_batch;   // per-lane fast path: lanes whose walk is over wait until this many are (RT_SHADE_BATCH)
     int32_t leaf_batch;    // per-lane fast path: lanes standing on a leaf wait until this many do (RT_LEAF_BATCH)
+    int32_t regroup_rounds; // per-lane block kernel: (two node steps + one leaf test) this many times between two regroups
 };
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -918,6 +919,245 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// render_fastlanes_block_kernel: the per-lane walk with the paths of a BLOCK regrouped every few node steps.
+// In render_fastlanes_kernel a lane whose walk is over waits, in its wave, until forty lanes do; a node step therefore
+// runs with 30 - 39 of a wave's 64 lanes on.  Here the four waves of a block trade paths through LDS after every round of
+// a few node steps and leaf tests -- finished walks first, then dead lanes, then the walks still under way -- so the
+// finished walks of all four waves are shaded together by whole waves, the dead lanes are refilled together, and the
+// other waves hold nothing but walks.  What moves is the path (ray, throughput, stream, depth) and its walk's cursor
+// (node, stack height, best hit): 16 dwords.  The stack does NOT move: it belongs to a HOME (one of the block's 256,
+// 16 bits per level), and the path carries its home's number, which is why the tree must have fewer than 32768 nodes
+// and leaves; 1/d, -o/d and d.d are recomputed after the move.  Work unit: a 16x16 tile x a range of samples, chained
+// like the block kernel's.
+// ---------------------------------------------------------------------------
+// Measured (round 3, profiles/r03_lanes_regroup_experiment.txt): node steps run with 45 - 50 of 64 lanes on instead of 32 - 37, but
+// a regroup costs about two node steps per lane and a walk changes state every four or five, and the leaf tests lose their
+// batching: random spheres 7.16 -> 6.4, Next-Week final 1.89 -> 1.49 Gpaths/s at the best cadence (6 - 12 rounds), only the
+// 4096-sphere field gains (2.27 -> 2.49).  So it is not the default; RT_OPT_LANES_REGROUP = 1 selects it.
+#ifndef RT_LANES_REGROUP_DEFAULT
+#define RT_LANES_REGROUP_DEFAULT 0
+#endif
+#ifndef RT_REGROUP_ROUNDS_DEFAULT
+#define RT_REGROUP_ROUNDS_DEFAULT 8
+#endif
+#ifndef RT_LANES_BLOCK_WAVES_PER_EU
+#define RT_LANES_BLOCK_WAVES_PER_EU 5
+#endif
+template <bool TEX, bool BOX>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(RT_LANES_BLOCK_WAVES_PER_EU, RT_LANES_BLOCK_WAVES_PER_EU)))
+void render_fastlanes_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf::Layout Y, RenderArgs A, float *__restrict__ accum,
+                                   unsigned *__restrict__ next_task)
+{
+    constexpr int NW = 4, NT = 64 * NW, TW = 16;
+    __shared__ float acc[3 * NT];
+    __shared__ uint4 xch[4][NT]; // the path and its walk's cursor in four 16-byte pieces, [piece][slot]
+    __shared__ int4 cnt[NW];     // [wave].{x,y,z} = lanes to shade, dead lanes, lanes whose walk is under way
+    __shared__ unsigned pool_next;
+    __shared__ int task_now;
+    __shared__ __align__(16) rt_camera lcam;
+    extern __shared__ short home_stacks[]; // [A.stack_levels][NT]: one stack per home
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int task = blockIdx.x;
+    if (tid < (int)(sizeof(rt_camera) / 4)) reinterpret_cast<uint32_t *>(&lcam)[tid] = reinterpret_cast<const uint32_t *>(&S.cam)[tid];
+
+    int tile_x, tile_y, s0, s1;
+    unsigned total;
+    uint32_t tile_word = 0u; // rt_pixel_word of the tile's first pixel (see render_fast_block_kernel)
+    constexpr uint32_t IN_TILE = (15u << 16) | (uint32_t)(TW - 1);
+    auto open_task = [&](int tk) {
+        const int tile = tk / A.n_chunks, chunk = tk - tile * A.n_chunks;
+        tile_y = tile / A.tiles_x, tile_x = tile - tile_y * A.tiles_x;
+        tile_word = rt_pixel_word((uint32_t)(tile_y * 16), (uint32_t)(tile_x * TW));
+        s0 = chunk * A.chunk_samples;
+        s1 = min(s0 + A.chunk_samples, A.n_samples);
+        total = tk < A.n_tasks ? (unsigned)NT * (unsigned)((s1 - s0) * A.sub_samples) : 0u;
+    };
+    open_task(task);
+    const float inv_nx = 1.0f / float(A.nx), inv_ny = 1.0f / float(A.ny), inv_sub = 1.0f / (float)A.sub_samples;
+    auto flush = [&](bool with_atomics) {
+        const int col = tile_x * TW + (tid % TW), row = tile_y * 16 + (tid / TW);
+        if (col < A.nx && row < A.ny) {
+            float *dst = accum + 4 * ((size_t)row * A.nx + col);
+            const float v4[4] = {(float)(s1 - s0), acc[2 * NT + tid] * inv_sub, acc[NT + tid] * inv_sub, acc[tid] * inv_sub};
+            if (with_atomics) {
+                for (int c = 0; c < 4; ++c) atomicAdd(dst + c, v4[c]);
+            } else {
+                *reinterpret_cast<float4 *>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            }
+        }
+    };
+    acc[tid] = 0.0f, acc[NT + tid] = 0.0f, acc[2 * NT + tid] = 0.0f;
+    if (tid == 0) pool_next = 0u;
+    __syncthreads();
+
+    bool alive = false;
+    Ray r = Ray{v3(0, 0, 0), v3(0, 0, 1), 0.0f};
+    V3 T = v3(1, 1, 1);
+    Rng rng{0u, 0u};
+    int depth = 0, home = tid, turn = 0;
+    rtf::Walk w;
+    rtf::walk_start(w, r, RT_FLT_MAX, false);
+#ifdef RT_COUNT_WALK
+    unsigned n_count[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#endif
+
+    for (;;) {
+        // ---- refill: the dead lanes (together after the regroup) take items from the block's pool and start their walks ----
+        const unsigned long long dead = __ballot(!alive);
+        if (dead != 0ull) {
+            unsigned base = 0u;
+            if (lane == 0) base = atomicAdd(&pool_next, (unsigned)__popcll(dead)); // may run past `total`; bounded by the host
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base < total) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+                const unsigned item = base + rank;
+                if (!alive && item < total) {
+                    const int pix = (int)(item % (unsigned)NT);
+                    const int q = (int)(item / (unsigned)NT);
+                    const int qs = A.sub_samples == 1 ? q : q / A.sub_samples;
+                    const int sample = A.sample_begin + s0 + qs;
+                    const int sub = q - qs * A.sub_samples;
+                    const int col = tile_x * TW + (pix % TW), row = tile_y * 16 + (pix / TW);
+                    if (col < A.nx && row < A.ny) {
+                        rng.start(rt_path_key(A.seed, (uint32_t)(sample * A.sub_samples + sub)), rt_pixel_word((uint32_t)row, (uint32_t)col));
+                        const int j = A.ny - 1 - row;
+                        const float u = (float(col) + rng.next()) * inv_nx;
+                        const float v = (float(j) + rng.next()) * inv_ny;
+                        const rt_camera cam = lcam;
+                        const V3 disk = cam.lens_radius == 0.0f ? v3(0, 0, 0) : rtf::rnd_unit_disk(rng); // include/rt_rng.h
+                        const float time01 = rng.next();
+                        r = rtf::camera_ray(cam, u, v, disk, time01);
+                        T = v3(1, 1, 1);
+                        depth = 0;
+                        alive = true;
+                        rtf::walk_start(w, r, RT_FLT_MAX, true);
+                        RT_COUNT(3, true);
+                        RT_COUNT(2, true);
+                    }
+                }
+            }
+        }
+
+        // ---- a round of the walks: A.regroup_rounds x (two node steps, one leaf test) ------------------------------------------
+        const rtf::HomeStack16 stack{home_stacks + home, NT};
+        for (int rep = 0; rep < A.regroup_rounds; ++rep) {
+            if (!__any(alive & (w.cur != RT_BVH_NONE))) break;
+#pragma unroll
+            for (int step = 0; step < 2; ++step) {
+                RT_COUNT(0, w.cur >= 0);
+                RT_COUNT_WAVE(4, __any(w.cur >= 0));
+                if (w.cur >= 0) rtf::walk_node(S, w, 0.001f, stack);
+            }
+            const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
+            RT_COUNT(1, at_leaf);
+            RT_COUNT_WAVE(5, __any(at_leaf));
+            if (at_leaf) rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack); // (a constant_medium draws, src/volume.h:43)
+        }
+
+        // ---- regroup: walks that are over first (to be shaded), then the dead lanes (to be refilled), then the walks under way ----
+        const int cls = !alive ? 1 : (w.cur == RT_BVH_NONE ? 0 : 2);
+        const unsigned long long b0 = __ballot(cls == 0), b1 = __ballot(cls == 1);
+        const unsigned long long mine = cls == 0 ? b0 : cls == 1 ? b1 : ~(b0 | b1);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+        if (lane == 0) cnt[wave] = make_int4(__popcll(b0), __popcll(b1), 64 - __popcll(b0 | b1), 0);
+        __syncthreads();
+        int tot0 = 0, n_dead = 0, low = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) {
+            const int4 n = cnt[w2];
+            const int same = cls == 0 ? n.x : cls == 1 ? n.y : n.z;
+            tot0 += n.x, n_dead += n.y;
+            low += w2 < wave ? same : 0;
+        }
+        const unsigned pool_now = pool_next; // stable between the two barriers: only the refill changes it
+        const int dst = (cls == 0 ? 0 : cls == 1 ? tot0 : tot0 + n_dead) + low + rank;
+        {
+            const uint32_t packed = (uint32_t)depth | ((uint32_t)w.sp << 16) | ((uint32_t)home << 21) | ((uint32_t)cls << 29);
+            xch[0][dst] = make_uint4(__float_as_uint(r.o.x), __float_as_uint(r.o.y), __float_as_uint(r.o.z), __float_as_uint(r.d.x));
+            xch[1][dst] = make_uint4(__float_as_uint(r.d.y), __float_as_uint(r.d.z), __float_as_uint(r.time), __float_as_uint(T.x));
+            xch[2][dst] = make_uint4(__float_as_uint(T.y), __float_as_uint(T.z), rng.x, rng.w);
+            xch[3][dst] = make_uint4(packed, (uint32_t)w.cur, __float_as_uint(w.best_t), (uint32_t)w.best_prim);
+        }
+        __syncthreads();
+        if (!A.chain && n_dead == NT && pool_now >= total) break; // the same for every wave of the block
+        // (read rotated by one wave more every round, so that every SIMD sees every kind of lane in turn)
+        const int slot = (tid + turn) & (NT - 1);
+        turn += 64;
+        int cls_in;
+        {
+            const uint4 q0 = xch[0][slot], q1 = xch[1][slot], q2 = xch[2][slot], q3 = xch[3][slot];
+            r.o = v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+            r.d = v3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+            r.time = __uint_as_float(q1.z);
+            T = v3(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.y));
+            rng.x = q2.z, rng.w = q2.w;
+            depth = (int)(q3.x & 0xffffu), home = (int)((q3.x >> 21) & 255u), cls_in = (int)(q3.x >> 29);
+            alive = cls_in != 1;
+            // the walk's cursor; what depends on the ray alone is made again for the walks under way
+            w.sp = (int)((q3.x >> 16) & 31u);
+            w.cur = cls_in == 2 ? (int)q3.y : RT_BVH_NONE;
+            w.best_t = __uint_as_float(q3.z), w.best_prim = (int)q3.w;
+            if (cls_in == 2) rtf::walk_ray_constants(w, r);
+        }
+        if (A.chain && pool_now >= total) { // the pool is empty (the same finding in every wave of the block)
+            if (task >= A.n_tasks) { // nothing left to take
+                if (n_dead == NT) break;
+            } else {
+                // the tile goes to the image and the next task opens; the paths still on their way find, when they end, that
+                // their pixel is not in the block's tile any more and add to the image themselves
+                flush(true); // (every thread reads and clears the sums of its own pixel only: no barrier in between)
+                acc[tid] = 0.0f, acc[NT + tid] = 0.0f, acc[2 * NT + tid] = 0.0f;
+                if (tid == 0) {
+                    task_now = (int)(atomicAdd(next_task, 1u) + gridDim.x);
+                    pool_next = 0u;
+                }
+                __syncthreads();
+                task = task_now;
+                open_task(task);
+            }
+        }
+
+        // ---- shade the walks that are over: whole waves of them ---------------------------------------------------------------
+        const bool to_shade = cls_in == 0;
+        RT_COUNT_WAVE(6, __any(to_shade));
+        RT_COUNT(7, to_shade);
+        if (to_shade) {
+            const bool hit_any = w.best_prim >= 0;
+            rtf::Surface sf;
+            sf.p = r.o; // a miss ends the path; shade still writes the (dead) ray from it
+            if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
+            V3 L;
+            if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
+                alive = false;
+                const uint32_t pw = rng.w;
+                if (A.chain && ((pw ^ tile_word) & ~IN_TILE) != 0u) { // a path of a tile that has gone to the image already
+                    float *dst2 = accum + 4 * ((size_t)(pw >> 16) * A.nx + (pw & 0xffffu));
+                    if (L.x == L.x && L.x != 0.0f) atomicAdd(dst2 + 3, L.x * inv_sub);
+                    if (L.y == L.y && L.y != 0.0f) atomicAdd(dst2 + 2, L.y * inv_sub);
+                    if (L.z == L.z && L.z != 0.0f) atomicAdd(dst2 + 1, L.z * inv_sub);
+                } else {
+                    const int pix = (int)(((pw >> 16) & 15u) * (uint32_t)TW + (pw & (uint32_t)(TW - 1)));
+                    if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
+                    if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[NT + pix], L.y);
+                    if (L.z == L.z && L.z != 0.0f) atomicAdd(&acc[2 * NT + pix], L.z);
+                }
+            } else {
+                rtf::walk_start(w, r, RT_FLT_MAX, true); // scattered: the new ray is in r
+                RT_COUNT(2, true);
+            }
+        }
+    }
+
+    if (!A.chain) flush(A.atomic_out != 0);
+    else flush(true); // the last tile (every other one went out when the block moved on)
+#ifdef RT_COUNT_WALK
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
+#endif
+}
+
 __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n, const float *__restrict__ rays, float t_min, float t_max,
                                                               uint32_t seed, int stack_levels, rt_hit *__restrict__ out)
 {
@@ -1133,6 +1373,7 @@ struct rt_scene {
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     bool lanes_boxes = false;   // its tree holds box leaves or media bounded by boxes (rt_box.h)
     int bvh_levels = 1;         // inner levels of that tree (rt_bvh_build)
+    bool lanes_small = false;   // that tree has fewer than 32767 nodes and leaves: its references fit the 16-bit home stacks of render_fastlanes_block_kernel
     const char *fast_why = "";
     rtf::Layout layout{0, 0, 0, 0, {0, 0, 0, 0}, 0, 0, 0u, 0.0f};
     uint32_t *d_records = nullptr; // 64 x 8 dwords, then 64 user ids and 64 x 6 face ids (inside blob)
@@ -1147,6 +1388,7 @@ struct rt_scene {
     // rt_scene_set_option: tuning / test switches of rt_render (0 = the library's choice)
     int opt_block_kernel = 1, opt_chain = 1, opt_target_tasks = 0, opt_paths_per_lane = 0, opt_node_steps = 0, opt_chain_blocks_per_cu = 0;
     int opt_shade_batch = 0, opt_leaf_batch = 0;
+    int opt_lanes_regroup = -1, opt_regroup_rounds = 0; // RT_OPT_LANES_REGROUP (-1: the library's choice), RT_OPT_REGROUP_ROUNDS
 };
 
 #define RT_HIP(call)                                                                                                   \
@@ -1391,6 +1633,7 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
         s->fast_textured |= (int32_t)tab.rec[tab.materials_base + m][1] >= 0;
     s->lanes_ok = lanes_ok;
     s->bvh_levels = lanes_ok && bvh_depth > 0 ? bvh_depth : 1;
+    s->lanes_small = lanes_ok && bvh.size() < 32767 && leaves.size() < 32767 && s->bvh_levels <= 31;
     for (const rt_prim &fp : fprims) s->lanes_boxes |= (fp.flags & RT_PRIM_IS_BOX) != 0;
     for (int m = 0; lanes_ok && m < d->n_materials; ++m)
         s->fast_textured |= d->materials[m].texture >= 0 && d->textures[d->materials[m].texture].kind != RT_TEX_CONSTANT;
@@ -1456,7 +1699,12 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     // and light list small enough for its packed state word)
     const bool block_off = s->opt_block_kernel == 0; // RT_OPT_BLOCK_KERNEL: the wave kernel instead
     const bool block_kernel = use_fast && s->fast_ok && !s->fast_textured && !block_off && p->max_depth < 65536 && s->layout.n_lights <= 16;
-    const int tile_w = block_kernel ? 4 * BLOCK_WAVES : 8, tile_h = block_kernel ? 16 : 8, waves_per_task = block_kernel ? BLOCK_WAVES : 1;
+    // the per-lane path has two kernels as well: one wave per 8x8 tile, or (trees whose references fit 16 bits) one block of four
+    // waves per 16x16 tile that regroups its paths every few node steps (render_fastlanes_block_kernel)
+    const bool lanes_block = use_fast && !s->fast_ok && s->lanes_ok && s->lanes_small && p->max_depth < 65536 &&
+                             (s->opt_lanes_regroup < 0 ? RT_LANES_REGROUP_DEFAULT : s->opt_lanes_regroup) != 0;
+    const bool tile16 = block_kernel || lanes_block;
+    const int tile_w = block_kernel ? 4 * BLOCK_WAVES : tile16 ? 16 : 8, tile_h = tile16 ? 16 : 8, waves_per_task = block_kernel ? BLOCK_WAVES : tile16 ? 4 : 1;
     RenderArgs A{};
     A.nx = p->nx, A.ny = p->ny;
     A.tiles_x = (p->nx + tile_w - 1) / tile_w, A.tiles_y = (p->ny + tile_h - 1) / tile_h;
@@ -1501,7 +1749,29 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     const int blocks = (A.n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     unsigned *const d_task_counter = s->d_task_counters + (s->launch_seq.fetch_add(1u) & 63u);
     RT_HIP(hipEventRecord(s->ev0, stream));
-    if (use_fast && s->lanes_ok) {
+    if (lanes_block) {
+        // one block per task, or (chained) as many blocks as the chip holds at once, each taking tasks from the counter
+        const size_t lds = (size_t)s->bvh_levels * 256 * sizeof(short); // the home stacks
+        A.stack_levels = s->bvh_levels;
+        A.regroup_rounds = s->opt_regroup_rounds > 0 ? s->opt_regroup_rounds : RT_REGROUP_ROUNDS_DEFAULT;
+#define RT_LAUNCH_LANES_BLOCK(TEX, BOX) \
+    do { \
+        dim3 gs((unsigned)A.n_tasks); \
+        int fit = 0; \
+        if (A.chain) { \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, render_fastlanes_block_kernel<TEX, BOX>, 256, lds) != hipSuccess || fit < 1) fit = 4; \
+            if (s->opt_chain_blocks_per_cu > 0) fit = s->opt_chain_blocks_per_cu; \
+            gs.x = (unsigned)std::min<int64_t>(A.n_tasks, (int64_t)s->n_cus * fit); \
+            RT_HIP(hipMemsetAsync(d_task_counter, 0, sizeof(unsigned), stream)); \
+        } \
+        hipLaunchKernelGGL((render_fastlanes_block_kernel<TEX, BOX>), gs, dim3(256), lds, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter); \
+    } while (0)
+        if (s->fast_textured && s->lanes_boxes) RT_LAUNCH_LANES_BLOCK(true, true);
+        else if (s->fast_textured) RT_LAUNCH_LANES_BLOCK(true, false);
+        else if (s->lanes_boxes) RT_LAUNCH_LANES_BLOCK(false, true);
+        else RT_LAUNCH_LANES_BLOCK(false, false);
+#undef RT_LAUNCH_LANES_BLOCK
+    } else if (use_fast && s->lanes_ok) {
         // chained: as many blocks as the chip holds at once (six waves per SIMD), each wave takes tasks from the counter
         int64_t per_cu = RT_LANES_WAVES_PER_EU;
         if (s->opt_chain_blocks_per_cu > 0) per_cu = s->opt_chain_blocks_per_cu; // RT_OPT_CHAIN_BLOCKS_PER_CU
@@ -1781,6 +2051,11 @@ extern "C" int rt_scene_set_option(rt_scene *s, int option, int value)
     case RT_OPT_LEAF_BATCH:
         if (value > 64) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: a batch is at most the 64 lanes of a wave");
         (option == RT_OPT_SHADE_BATCH ? s->opt_shade_batch : s->opt_leaf_batch) = value;
+        return RT_OK;
+    case RT_OPT_LANES_REGROUP: s->opt_lanes_regroup = value != 0; return RT_OK;
+    case RT_OPT_REGROUP_ROUNDS:
+        if (value > 64) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: at most 64 walk rounds between two regroups");
+        s->opt_regroup_rounds = value;
         return RT_OK;
     case RT_OPT_CHAIN_BLOCKS_PER_CU:
         if (value > 64) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: at most 64 blocks per CU");

@@ -124,6 +124,14 @@ struct Walk {
                    // cancel to NaN; min/max drop a NaN, which only ever makes a box easier to enter.
     float dd, inv_dd; // d.d (chains are rigid: the same in every space)
 };
+// what a walk keeps about its ray (also made again when a walk under way moves to another lane)
+RTF_DEV void walk_ray_constants(Walk &w, const Ray &wr)
+{
+    w.winv = rcp3(wr.d);
+    w.noi = v3(-wr.o.x * w.winv.x, -wr.o.y * w.winv.y, -wr.o.z * w.winv.z);
+    w.dd = ref_dot(wr.d, wr.d);
+    w.inv_dd = rcp(w.dd);
+}
 RTF_DEV void walk_start(Walk &w, const Ray &wr, float t_max, bool go)
 {
     w.cur = go ? 0 : RT_BVH_NONE;
@@ -135,7 +143,21 @@ RTF_DEV void walk_start(Walk &w, const Ray &wr, float t_max, bool go)
     w.dd = ref_dot(wr.d, wr.d); // as src/sphere.h:27 rounds it: it enters the sign of the discriminant (sphere_disc)
     w.inv_dd = rcp(w.dd);
 }
-RTF_DEV int walk_pop(Walk &w, const int *stack) { return w.sp > 0 ? stack[--w.sp * 64] : RT_BVH_NONE; }
+// Where a lane keeps its pending children.  The walk only pushes and pops, so the stack is a policy:
+//   int *                one dword per level, [level][lane] of the lane's wave (the lane's place in its wave never changes)
+//   rtf::HomeStack16     16 bits per level, [level][home] of the block: the stack stays where it is when the PATH moves to
+//                        another lane (render_fastlanes_block_kernel: `home` travels with the path); trees of fewer than
+//                        32768 nodes and leaves
+RTF_DEV void stack_push(int *stack, int &sp, int ref) { stack[sp++ * 64] = ref; }
+RTF_DEV int stack_pop(const int *stack, int &sp) { return sp > 0 ? stack[--sp * 64] : RT_BVH_NONE; }
+struct HomeStack16 {
+    short *base; // the block's stacks + the path's home
+    int stride;  // homes per level (threads of the block)
+};
+RTF_DEV void stack_push(HomeStack16 st, int &sp, int ref) { st.base[sp++ * st.stride] = (short)ref; }
+RTF_DEV int stack_pop(HomeStack16 st, int &sp) { return sp > 0 ? (int)st.base[--sp * st.stride] : RT_BVH_NONE; }
+template <class ST>
+RTF_DEV int walk_pop(Walk &w, ST stack) { return stack_pop(stack, w.sp); }
 
 // t of the plane stored as a half in the low / high 16 bits of w: ONE v_fma_mix_f32 (half * float + float)
 RTF_DEV float plane_lo(uint32_t w, float inv, float noi) { return fmaf(__half2float(__ushort_as_half((unsigned short)(w & 0xffffu))), inv, noi); }
@@ -143,7 +165,8 @@ RTF_DEV float plane_hi(uint32_t w, float inv, float noi) { return fmaf(__half2fl
 
 // lanes with cur >= 0: both children's boxes of node cur (32 bytes: half-float boxes, rt_bvh.h), far bound = best hit
 // so far; nearer child next, the other pushed
-RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, int *stack)
+template <class ST>
+RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
 {
     const uint4 *q = reinterpret_cast<const uint4 *>(S.bvh + w.cur);
     const uint4 a = q[0], b = q[1]; // {lo.x|lo.y, lo.z|hi.x, hi.y|hi.z, ref} per child
@@ -164,7 +187,7 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, int *stack)
     const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
     const bool hn = first0 ? h0 : h1, hf = first0 ? h1 : h0;
     if (hn & hf) {
-        stack[w.sp++ * 64] = far;
+        stack_push(stack, w.sp, far);
         w.cur = near;
     } else if (hn | hf) {
         w.cur = hn ? near : far;
@@ -176,8 +199,8 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, int *stack)
 // lanes with cur < 0 (and not NONE): leaf ~cur (rt_bvh.h: 32 bytes, what the test of a sphere or rect reads) against
 // the lane's ray.  best_prim receives the leaf's rt_prim index.
 // BOX: the tree may hold box leaves / media bounded by boxes (scenes without them skip that code altogether)
-template <bool BOX>
-RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, int *stack)
+template <bool BOX, class ST>
+RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, ST stack)
 {
     const uint4 *q = reinterpret_cast<const uint4 *>(S.leaves + ~w.cur);
     const uint4 la = q[0], lb = q[1]; // f0 f1 f2 f3 | f4 kind_chain prim visits

@@ -237,6 +237,26 @@ def test_chained_tasks_trace_the_same_paths(scene, nx, ny, ns):
     assert np.allclose(chained, again, rtol=2e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("scene,nx,ny,ns", [("random_spheres", 72, 40, 24), ("cornell_box_volumes", 40, 40, 24), ("next_week_final", 48, 48, 8),
+                                             ("sphere_field_4k", 40, 24, 8)])
+def test_regrouping_per_lane_kernel_traces_the_same_paths(scene, nx, ny, ns):
+    """RT_OPT_LANES_REGROUP = 1: render_fastlanes_block_kernel, where the four waves of a block trade paths (and the cursors of the
+    walks under way) through LDS every few node steps.  A path's draws and the order of its leaf visits do not depend on the lane
+    that carries it, so the image equals the wave kernel's up to float summation order -- media included -- at any cadence,
+    chained or not."""
+    sc = Scene(HostScene(scene, nx / ny), 0)
+    wave = gpu_render(sc, nx, ny, 0, ns, seed=13)
+    assert sc.info(_capi.RT_INFO_RECORDS) == -1 and sc.info(_capi.RT_INFO_LAST_RENDER_PATH) == _capi.RT_PATH_FAST
+    sc.set_option(_capi.RT_OPT_LANES_REGROUP, 1)
+    for rounds, chain in ((0, 1), (1, 1), (3, 0)):
+        sc.set_option(_capi.RT_OPT_REGROUP_ROUNDS, rounds)
+        sc.set_option(_capi.RT_OPT_CHAIN_TASKS, chain)
+        block = gpu_render(sc, nx, ny, 0, ns, seed=13)
+        assert np.all(block[..., 0] == ns)
+        assert np.allclose(block, wave, rtol=2e-5, atol=1e-5), (rounds, chain, np.abs(block - wave).max())
+    sc.close()
+
+
 def test_generic_scan_with_box_records_matches_oracle():
     """Scenes of more than 16 primitives keep their box records in the record table and are scanned by the generic loop
     (lanes that miss a box skip its subtree).  No built-in scene of that size fits the table, so the Cornell box is built
