@@ -414,7 +414,8 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     static_assert((TW & (TW - 1)) == 0 && TW <= 32, "the tile-local index is cut out of the pixel word with masks");
     __shared__ float acc[3 * NT];
     __shared__ uint4 xch[3][NT]; // the path state in three 16-byte pieces, [piece][slot]
-    __shared__ int4 cnt[NW];     // [wave].{x,y,z,w} = lanes of class 0..3
+    __shared__ uint2 fronts[4];  // [round & 3].{x,y} = slots taken so far from the bottom (specular) and from the top (diffuse)
+    __shared__ unsigned pool_seen[4]; // [round & 3]: the block's one reading of pool_next in that round
     __shared__ unsigned pool_next;
     __shared__ int task_now;     // the task the pool belongs to (CHAIN)
     __shared__ uint32_t lrecs[(RT_REC_MAX + 1) * 8]; // the record table as rtf::stage_records lays it out: read by the scan (broadcast)
@@ -464,6 +465,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     };
     acc[tid] = 0.0f, acc[NT + tid] = 0.0f, acc[2 * NT + tid] = 0.0f;
     if (tid == 0) pool_next = 0u;
+    if (tid < 4) fronts[tid] = make_uint2(0u, 0u);
     __syncthreads();
 
     bool alive = false;
@@ -471,7 +473,7 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     float time = 0.0f;
     Rng rng{0u, 0u};
     int depth = 0;
-    int turn = 0;
+    int turn = 0, rk = 0;
 #ifdef RT_COUNT_SHADE
     unsigned sc[16] = {0u};
 #endif
@@ -574,60 +576,65 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
             }
         }
 
-        // ---- regroup by class ----------------------------------------------------------------------------------------------
+        // ---- regroup by class: ONE barrier ---------------------------------------------------------------------------------
+        // The specular lanes take slots from the bottom of the exchange upwards, the diffuse lanes (within a wave: those that
+        // sample a rect light, then the others) from the top downwards, each wave with one LDS atomic per end; what lies
+        // between the two fronts is the dead lanes' -- they have no state to hand over and write nothing.  Nobody needs the
+        // other waves' counts before writing, so the round has one barrier, after the writes; behind it the two totals say
+        // what every slot holds.  (Round 2 published per-wave counts, waited, computed a prefix over 4 x 4 counts and waited
+        // again: 40 vector instructions and a barrier more per round.)  The counters are used in turn, four sets: the set of
+        // the next round is cleared before this round's barrier, when its last readers (two rounds back) are long gone.
         const unsigned long long b0 = __ballot(cls == 0), b1 = __ballot(cls == 1), b2 = __ballot(cls == 2);
-        const unsigned long long mine = cls == 0 ? b0 : cls == 1 ? b1 : cls == 2 ? b2 : ~(b0 | b1 | b2);
-        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-        if (lane == 0) cnt[wave] = make_int4(__popcll(b0), __popcll(b1), __popcll(b2), 64 - __popcll(b0 | b1 | b2));
-        __syncthreads();
-        // Slots: the specular lanes first, then as many of the dead lanes as it takes to fill their last wave, then the
-        // diffuse lanes (rect light, then axis sampling), then the other dead lanes.  The padding keeps specular and diffuse
-        // lanes out of each other's waves: a wave that holds both runs both scatter functions, each with part of its lanes.
-        int tot0 = 0, tot1 = 0, tot2 = 0, n_dead = 0, low = 0; // class totals; lanes of my class in lower waves
-#pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) {
-            const int4 n = cnt[w2];
-            const int same = cls == 0 ? n.x : cls == 1 ? n.y : cls == 2 ? n.z : n.w;
-            tot0 += n.x, tot1 += n.y, tot2 += n.z, n_dead += n.w;
-            low += w2 < wave ? same : 0;
+        const int n0 = __popcll(b0), n1 = __popcll(b1), n12 = __popcll(b1 | b2);
+        unsigned base_spec = 0u, base_diff = 0u;
+        if (lane == 0) {
+            base_spec = atomicAdd(&fronts[rk].x, (unsigned)n0);
+            base_diff = atomicAdd(&fronts[rk].y, (unsigned)n12);
         }
-#ifdef RT_NO_SPEC_PADDING
-        const int pad = 0;
-#else
-        const int pad = min(n_dead, (64 - (tot0 & 63)) & 63);
-#endif
-        const unsigned pool_now = pool_next; // stable between the two barriers: only the refill changes it
-        const int g = low + rank;
-        const int dst = cls == 0 ? g : cls == 1 ? tot0 + pad + g : cls == 2 ? tot0 + pad + tot1 + g : g < pad ? tot0 + g : tot0 + tot1 + tot2 + g;
-        // (the ray's time is not carried: nothing the record table can hold -- static spheres and rects -- reads it)
-        // the record that was hit travels as its index and whether it is a box (where its key lies in the LDS copy)
-        const uint32_t rec_bits = hit ? (RT_KEY_INDEX(key) | ((key & 15u) == RT_REC_BOX ? 64u : 0u)) : 0u;
-        const uint32_t packed = (uint32_t)depth | ((uint32_t)cls << 16) | ((uint32_t)to_light << 18) | ((uint32_t)light << 19) | (rec_bits << 23);
-        xch[0][dst] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(d.x));
-        xch[1][dst] = make_uint4(__float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(T.x), __float_as_uint(T.y));
-        xch[2][dst] = make_uint4(__float_as_uint(T.z), rng.x, packed, rng.w);
+        base_spec = __builtin_amdgcn_readfirstlane(base_spec), base_diff = __builtin_amdgcn_readfirstlane(base_diff);
+        const unsigned long long mine = cls == 0 ? b0 : cls == 1 ? b1 : b2;
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+        const int dst = cls == 0 ? (int)base_spec + rank : NT - 1 - ((int)base_diff + (cls == 2 ? n1 : 0) + rank);
+        if (cls != 3) {
+            // (the ray's time is not carried: nothing the record table can hold -- static spheres and rects -- reads it)
+            // the record that was hit travels as its index and whether it is a box (where its key lies in the LDS copy)
+            const uint32_t rec_bits = RT_KEY_INDEX(key) | ((key & 15u) == RT_REC_BOX ? 64u : 0u);
+            const uint32_t packed = (uint32_t)depth | ((uint32_t)cls << 16) | ((uint32_t)to_light << 18) | ((uint32_t)light << 19) | (rec_bits << 23);
+            xch[0][dst] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(d.x));
+            xch[1][dst] = make_uint4(__float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(T.x), __float_as_uint(T.y));
+            xch[2][dst] = make_uint4(__float_as_uint(T.z), rng.x, packed, rng.w);
+        }
+        if (tid == 0) {
+            fronts[(rk + 1) & 3] = make_uint2(0u, 0u);
+            pool_seen[rk] = pool_next; // ONE reading of the pool for the whole block (the refills of this round may still be coming
+                                       // in: the pool only shrinks, so a stale reading delays the block's decisions by a round at most)
+        }
         __syncthreads();
-        if (!CHAIN && n_dead == NT && pool_now >= total) break; // the same for every wave of the block
+        const uint2 front = fronts[rk];
+        const unsigned pool_now = pool_seen[rk];
+        rk = (rk + 1) & 3;
+        const bool none_alive = front.x + front.y == 0u;
+        if (!CHAIN && none_alive && pool_now >= total) break; // the same for every wave of the block
         // The slots are sorted by class, so read in place wave 0 would always get the costliest paths and the last wave the
         // waiting lanes -- and a block's waves sit on different SIMDs.  The block therefore reads the slots rotated by one
         // wave more every round: each SIMD sees every class in turn.
         const int slot = (tid + turn) & (NT - 1);
         turn += 64;
         const uint4 q0 = xch[0][slot], q1 = xch[1][slot], q2 = xch[2][slot];
+        alive = (slot < (int)front.x) | (slot >= NT - (int)front.y); // between the fronts: nobody's (what the slot holds is stale)
         p = v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
         d = v3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
         T = v3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
         rng.x = q2.y, rng.w = q2.w;
         const uint32_t word = q2.z;
-        depth = (int)(word & 0xffffu), cls = (int)((word >> 16) & 3u);
+        depth = (int)(word & 0xffffu), cls = alive ? (int)((word >> 16) & 3u) : 3;
         to_light = (int)((word >> 18) & 1u), light = (int)((word >> 19) & 15u);
         const int hit_rec = (int)((word >> 23) & 63u);
         const bool hit_box = ((word >> 29) & 1u) != 0u;
-        alive = cls != 3;
         o = p;
         if (CHAIN && pool_now >= total) { // the pool is empty (the same finding in every wave of the block)
             if (task >= A.n_tasks) { // nothing left to take
-                if (n_dead == NT) break;
+                if (none_alive) break;
             } else {
                 // the tile goes to the image and the next task opens; the paths still on their way find, when they end, that
                 // their pixel is not in the block's tile any more and add to the image themselves
