@@ -5,7 +5,7 @@
 tag=$1; cfg=${2:-c2}
 out=$PWD/gpurun_out/prof_$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu"
+B="python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu --no-extra"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B > $out/trace.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $out/pmc1 -- $B > $out/pmc1.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_WAVES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc2 -- $B > $out/pmc2.log 2>&1 || exit 1
