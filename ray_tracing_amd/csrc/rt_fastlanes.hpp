@@ -168,7 +168,9 @@ RTF_DEV float plane_hi(uint32_t w, float inv, float noi) { return fmaf(__half2fl
 template <class ST>
 RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
 {
-    const uint4 *q = reinterpret_cast<const uint4 *>(S.bvh + w.cur);
+    // (a 32-bit byte offset from the table's base: the load takes the base from scalar registers, the lane computes one shift;
+    // trees are far below 4 GiB -- 4M primitives are 256 MiB)
+    const uint4 *q = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.bvh) + ((uint32_t)w.cur << 5));
     const uint4 a = q[0], b = q[1]; // {lo.x|lo.y, lo.z|hi.x, hi.y|hi.z, ref} per child
     const V3 i = w.winv, n = w.noi;
     const float x00 = plane_lo(a.x, i.x, n.x), y00 = plane_hi(a.x, i.y, n.y), z00 = plane_lo(a.y, i.z, n.z);
@@ -181,19 +183,20 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
     const float tf1 = fminf(fmin3(fmaxf(x10, x11), fmaxf(y10, y11), fmaxf(z10, z11)), w.best_t);
     const int ref0 = (int)a.w, ref1 = (int)b.w;
     const bool h0 = tf0 >= tn0, h1 = (tf1 >= tn1) & (ref1 != RT_BVH_NONE);
-// (a ray that starts inside both boxes enters both at t_min: the box it leaves first -- the tighter one -- goes first;
-    // random spheres +2 %, 1M spheres +1 %)
-    const bool first0 = (tn0 < tn1) | ((tn0 == tn1) & (tf0 <= tf1));
+    // "First" is the box to open now: the only one that was hit, or of two the nearer.  It is to be opened if either was hit
+    // and the other one pushed if both were -- said with lane masks and scalar logic only (selects between booleans, as in
+    // "was the nearer one hit", make the compiler turn them into 0 / 1 registers and back: a dozen vector instructions per
+    // step; and a select on the distances instead, "a missed box is infinitely far", costs the kernels with box leaves 30
+    // bytes of spills per lane).
+    // A ray that starts inside both boxes enters both at t_min: the box it leaves first -- the tighter one -- goes first
+    // (random spheres +2 %, 1M spheres +1 %).
+    const bool first0 = h0 & (!h1 | (tn0 < tn1) | ((tn0 == tn1) & (tf0 <= tf1)));
     const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
-    const bool hn = first0 ? h0 : h1, hf = first0 ? h1 : h0;
-    if (hn & hf) {
-        stack_push(stack, w.sp, far);
-        w.cur = near;
-    } else if (hn | hf) {
-        w.cur = hn ? near : far;
-    } else {
-        w.cur = walk_pop(w, stack);
-    }
+    const bool hit_near = h0 | h1, hit_far = h0 & h1;
+    if (hit_far) stack_push(stack, w.sp, far);
+    int next = near;
+    if (!hit_near) next = walk_pop(w, stack);
+    w.cur = next;
 }
 
 // lanes with cur < 0 (and not NONE): leaf ~cur (rt_bvh.h: 32 bytes, what the test of a sphere or rect reads) against
@@ -202,7 +205,7 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
 template <bool BOX, class ST>
 RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, ST stack)
 {
-    const uint4 *q = reinterpret_cast<const uint4 *>(S.leaves + ~w.cur);
+    const uint4 *q = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.leaves) + ((uint32_t)~w.cur << 5));
     const uint4 la = q[0], lb = q[1]; // f0 f1 f2 f3 | f4 kind_chain prim visits
     const int kind = (int)(lb.y & 255u), chain = (int)(lb.y >> 8);
     Ray lr = wr;
