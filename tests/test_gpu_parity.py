@@ -742,3 +742,42 @@ def test_baseline_configs_1_and_3_at_their_full_image_size(scene, nx, ny):
     sc.close()
     m_full, m_small = full[..., 1:].mean(axis=(0, 1)) / spp, small[..., 1:].mean(axis=(0, 1)) / 64
     assert np.allclose(m_full, m_small, rtol=0.05), (m_full, m_small)
+
+
+@pytest.mark.parametrize("scene,lo,hi", [("cornell_box_volumes", 0.0, 555.0), ("next_week_final", 0.0, 555.0)])
+def test_fast_path_medium_free_flight_has_the_oracles_distribution(scene, lo, hi):
+    """constant_medium::hit (src/volume.h:23-53) on the per-lane fast path, where it is NOT the exact path's code: the boundary's
+    two hits come from a slab test (smoke boxes) or two sphere tests, the free-flight distance from the hardware log, a lone child
+    of a bvh_node draws twice, and a medium behind the best hit is not visited.  The hit distance is random, so it is compared as a
+    distribution: for every medium of the scene, the t of the rays that end in it on the fast path against the oracle's (another
+    random stream), two-sample Kolmogorov-Smirnov; and the share of the rays each medium takes."""
+    from scipy.stats import ks_2samp
+    hs = HostScene(scene, 1.0)
+    sc = Scene(hs, 0)
+    rng = np.random.default_rng(23)
+    n = 120000
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    if scene == "next_week_final":
+        o[:, 1] = 110.0 + o[:, 1] * 0.8
+        o[: n // 2] = (np.array([360.0, 150.0, 145.0]) + rng.normal(size=(n // 2, 3)) * 45.0).astype(np.float32)  # in and around the blue sphere
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays = np.concatenate([o, d, rng.uniform(size=(n, 1)).astype(np.float32)], axis=1)
+    sc.set_path(trace=_capi.RT_PATH_FAST)
+    fast = api.trace_rays(sc, rays, seed=41)
+    sc.close()
+    cpu = O.trace_rays(hs, rays, seed=77)
+    desc = hs.desc.contents
+    iso = np.array([desc.materials[i].kind == _capi.RT_MAT_ISOTROPIC for i in range(desc.n_materials)])
+    fm = (fast["material"] >= 0) & iso[np.maximum(fast["material"], 0)]
+    cm = (cpu["material"] >= 0) & iso[np.maximum(cpu["material"], 0)]
+    assert cm.mean() > 0.05, cm.mean()
+    checked = 0
+    for pid in np.unique(cpu["prim_id"][cm]):
+        a, b = fast["t"][fm & (fast["prim_id"] == pid)], cpu["t"][cm & (cpu["prim_id"] == pid)]
+        share_f, share_c = len(a) / n, len(b) / n
+        assert abs(share_f - share_c) <= 4.0 * np.sqrt(max(share_c, 1e-4) / n) + 5e-4, (pid, share_f, share_c)
+        if len(b) >= 400:
+            p = ks_2samp(a.astype(np.float64), b.astype(np.float64)).pvalue
+            assert p > 1e-4, f"{scene} medium {pid}: t differs in distribution (KS p = {p:.2e}, {len(a)} vs {len(b)} rays)"
+            checked += 1
+    assert checked >= 1
