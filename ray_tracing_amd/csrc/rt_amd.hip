@@ -424,7 +424,6 @@ void render_fast_block_kernel(DevScene S, const uint32_t *__restrict__ recs, rtf
     // (the kernel is held to 80 SGPRs for eight waves per SIMD)
     __shared__ __align__(16) rt_camera lcam;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int task = blockIdx.x; // CHAIN: the first one; the counter hands out gridDim.x, gridDim.x + 1, ...
     rtf::stage_records(recs, lrecs, Y.n_stream, tid, NT);
     if (tid < (int)(sizeof(rt_camera) / 4)) reinterpret_cast<uint32_t *>(&lcam)[tid] = reinterpret_cast<const uint32_t *>(&S.cam)[tid];

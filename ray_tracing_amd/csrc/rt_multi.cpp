@@ -215,6 +215,7 @@ extern "C" int rt_multi_render_to_host(rt_multi *m, const rt_render_params *p, f
     const size_t npix = (size_t)p->nx * p->ny, bytes = npix * 16;
     // the accumulators and the 8-bit image grow to the largest image seen and are kept
     if (npix > m->cap_pixels) {
+        m->cap_pixels = 0; // until every buffer below exists: a failure half-way must not leave the old capacity standing
         for (Rank &k : m->ranks) {
             RTM_HIP(hipSetDevice(k.device));
             if (k.d_accum) (void)hipFree(k.d_accum);
@@ -224,7 +225,6 @@ extern "C" int rt_multi_render_to_host(rt_multi *m, const rt_render_params *p, f
         RTM_HIP(hipSetDevice(m->ranks[0].device));
         if (m->d_image) (void)hipFree(m->d_image);
         m->d_image = nullptr;
-        m->cap_pixels = 0;
         RTM_HIP(hipMalloc(&m->d_image, npix * 4));
         m->cap_pixels = npix;
     }
