@@ -774,6 +774,9 @@ __device__ unsigned long long g_walk_counts[8];
 #define RT_COUNT(k, cond)
 #define RT_COUNT_WAVE(k, any)
 #endif
+#ifdef RT_TIME_PHASES
+__device__ unsigned long long g_phase_cycles[4]; // [0] looks + shade + refill, [1] node steps, [2] leaf tests: wave cycles
+#endif
 template <bool TEX, bool BOX, int STEPS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 __attribute__((amdgpu_waves_per_eu(RT_LANES_WAVES_PER_EU, RT_LANES_WAVES_PER_EU)))
@@ -822,6 +825,12 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     unsigned n_count[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #endif
 
+#ifdef RT_TIME_PHASES // development (tools/phase_times.py): cycles a wave spends in each phase of the loop
+    unsigned long long tp[4] = {0ull, 0ull, 0ull, 0ull}, tp_mark = clock64();
+#define RT_PHASE(k) do { const unsigned long long now_ = clock64(); tp[k] += now_ - tp_mark; tp_mark = now_; } while (0)
+#else
+#define RT_PHASE(k)
+#endif
     for (;;) {
         // ---- lanes whose walk is over: shade, refill, start the next walk ----------------------
         const bool waiting = alive & (w.cur == RT_BVH_NONE);
@@ -902,6 +911,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                 continue; // only out-of-image pixels were drawn; draw again
             }
         }
+        RT_PHASE(0); // looks, shade, refill
         // ---- the walks ------------------------------------------------------------------------------
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
@@ -909,6 +919,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
             RT_COUNT_WAVE(4, __any(w.cur >= 0));
             if (w.cur >= 0) rtf::walk_node(S, w, 0.001f, stack);
         }
+        RT_PHASE(1); // node steps
         const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
         if (__popcll(__ballot(at_leaf)) >= A.leaf_batch || !__any(w.cur >= 0)) {
             RT_COUNT(1, at_leaf);
@@ -917,9 +928,15 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                 rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
             }
         }
+        RT_PHASE(2); // leaf tests
     }
 
     flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
+#ifdef RT_TIME_PHASES
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) atomicAdd(&g_phase_cycles[k], tp[k]);
+#endif
+#undef RT_PHASE
 #ifdef RT_COUNT_WALK
     for (int k = 0; k < 8; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
 #endif
@@ -1377,7 +1394,7 @@ struct rt_scene {
     bool fast_textured = false; // some material's texture is not a constant
     bool fast_flat = false;     // the record stream holds no box records and is stored in runs
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
-    bool lanes_boxes = false;   // its tree holds box leaves or media bounded by boxes (rt_box.h)
+    bool lanes_boxes = false;   // its tree holds leaves other than static spheres and rects: boxes (rt_box.h), media, moving spheres
     int bvh_levels = 1;         // inner levels of that tree (rt_bvh_build)
     bool lanes_small = false;   // that tree has fewer than 32767 nodes and leaves: its references fit the 16-bit home stacks of render_fastlanes_block_kernel
     const char *fast_why = "";
@@ -1640,7 +1657,10 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
     s->lanes_ok = lanes_ok;
     s->bvh_levels = lanes_ok && bvh_depth > 0 ? bvh_depth : 1;
     s->lanes_small = lanes_ok && bvh.size() < 32767 && leaves.size() < 32767 && s->bvh_levels <= 31;
-    for (const rt_prim &fp : fprims) s->lanes_boxes |= (fp.flags & RT_PRIM_IS_BOX) != 0;
+    for (const rt_leaf &lf : leaves) { // anything but static spheres and rects: the kernels with the rest of walk_leaf
+        const uint32_t k = lf.kind_chain & 255u;
+        s->lanes_boxes |= !(k == RT_PRIM_SPHERE || k == RT_PRIM_XY_RECT || k == RT_PRIM_XZ_RECT || k == RT_PRIM_YZ_RECT);
+    }
     for (int m = 0; lanes_ok && m < d->n_materials; ++m)
         s->fast_textured |= d->materials[m].texture >= 0 && d->textures[d->materials[m].texture].kind != RT_TEX_CONSTANT;
     s->d_records = (uint32_t *)(b + parts[8].off);
@@ -2080,6 +2100,19 @@ extern "C" int rt_debug_walk_counts(unsigned long long *out8, int reset)
     RT_HIP(hipDeviceSynchronize());
     if (out8) RT_HIP(hipMemcpy(out8, p, 64, hipMemcpyDeviceToHost));
     if (reset) RT_HIP(hipMemset(p, 0, 64));
+    return RT_OK;
+}
+#endif
+
+#ifdef RT_TIME_PHASES
+// development builds only (tools/phase_times.py): wave cycles per phase of render_fastlanes_kernel since the last reset
+extern "C" int rt_debug_phase_cycles(unsigned long long *out4, int reset)
+{
+    void *p = nullptr;
+    RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_cycles)));
+    RT_HIP(hipDeviceSynchronize());
+    if (out4) RT_HIP(hipMemcpy(out4, p, 32, hipMemcpyDeviceToHost));
+    if (reset) RT_HIP(hipMemset(p, 0, 32));
     return RT_OK;
 }
 #endif

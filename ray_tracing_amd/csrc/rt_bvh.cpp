@@ -343,8 +343,31 @@ bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::
         lf.prim = pi;
         lf.visits = p.reserved;
         if (p.kind == RT_PRIM_GROUP) memcpy(&lf.visits, &p.f[5], 4); // a box: p1.z in the last word (visits do not matter to a surface)
+        // self-contained forms (rt_bvh.h): a medium inside a sphere or a box, a moving sphere
+        rt_leaf ext{};
+        bool two = false;
+        if (p.kind == RT_PRIM_MEDIUM && shape.kind == RT_PRIM_SPHERE) {
+            for (int k = 0; k < 4; ++k) lf.f[k] = shape.f[k];
+            lf.f[4] = p.f[0]; // density
+            lf.kind_chain = (uint32_t)RT_LEAF_MEDIUM_SPHERE | ((uint32_t)shape.chain << 8);
+        } else if (p.kind == RT_PRIM_MEDIUM && shape.kind == RT_PRIM_GROUP && (shape.flags & RT_PRIM_IS_BOX)) {
+            for (int k = 0; k < 5; ++k) lf.f[k] = shape.f[k];
+            memcpy(&lf.visits, &shape.f[5], 4);
+            lf.kind_chain = (uint32_t)RT_LEAF_MEDIUM_BOX | ((uint32_t)shape.chain << 8);
+            ext.f[0] = p.f[0], ext.visits = p.reserved, ext.prim = pi, ext.kind_chain = lf.kind_chain;
+            two = true;
+        } else if (p.kind == RT_PRIM_MOVING_SPHERE) { // f = c0 c1 r t0 t1 (include/rt_amd.h)
+            lf.f[0] = p.f[0], lf.f[1] = p.f[1], lf.f[2] = p.f[2], lf.f[3] = p.f[6], lf.f[4] = p.f[7];
+            const float inv_dt = 1.0f / (p.f[8] - p.f[7]);
+            memcpy(&lf.visits, &inv_dt, 4);
+            lf.kind_chain = (uint32_t)RT_LEAF_MOVING_SPHERE | ((uint32_t)shape.chain << 8);
+            ext.f[0] = p.f[3] - p.f[0], ext.f[1] = p.f[4] - p.f[1], ext.f[2] = p.f[5] - p.f[2], ext.prim = pi, ext.kind_chain = lf.kind_chain;
+            two = true;
+        }
         leaves.push_back(lf);
-        return ~(int32_t)(leaves.size() - 1);
+        const int32_t leaf_ref = ~(int32_t)(leaves.size() - 1);
+        if (two) leaves.push_back(ext);
+        return leaf_ref;
     };
     nodes.resize(tree.size());
     for (size_t i = 0; i < tree.size(); ++i) {

@@ -44,6 +44,18 @@ typedef struct rt_bvh_node {
  * what the intersection test reads, and the rt_prim the hit is built from afterwards.
  *   sphere: f = cx cy cz r    rect: f = a0 a1 b0 b1 k    moving sphere, constant_medium: the test reads prims[prim]
  *   box (a GROUP that rt_box.h recognises): f = p0.x p0.y p0.z p1.x p1.y and p1.z in the last word */
+/* Leaf kinds beyond rt_prim_kind (the low byte of kind_chain): leaves that carry everything their test reads, so that the walk
+ * does not follow the leaf with dependent fetches of the 80-byte primitive and of its boundary (round 3: on Next-Week final the
+ * leaf tests were 38 % of the waves' time, most of it two media that every ray meets; on the book-1 scene most spheres move).
+ *   RT_LEAF_MEDIUM_SPHERE  a constant_medium whose boundary is a static sphere: f = cx cy cz r density, visits as usual
+ *   RT_LEAF_MEDIUM_BOX     ... whose boundary is a box (rt_box.h): f = p0.x p0.y p0.z p1.x p1.y, p1.z in the last word; TWO slots:
+ *                          the next one holds f[0] = density, visits in its last word
+ *   RT_LEAF_MOVING_SPHERE  f = c0.x c0.y c0.z r t0, 1 / (t1 - t0) in the last word; TWO slots: the next one holds f = c1 - c0
+ * Any other constant_medium (a boundary that is neither) and anything else keeps its rt_prim_kind and reads prims[prim]. */
+#define RT_LEAF_MEDIUM_SPHERE 16
+#define RT_LEAF_MEDIUM_BOX 17
+#define RT_LEAF_MOVING_SPHERE 18
+
 typedef struct rt_leaf {
     float    f[5];
     uint32_t kind_chain; /* rt_prim_kind | instance chain << 8 (of the shape; 0 = world space) */

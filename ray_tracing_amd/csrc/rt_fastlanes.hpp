@@ -201,7 +201,8 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
 
 // lanes with cur < 0 (and not NONE): leaf ~cur (rt_bvh.h: 32 bytes, what the test of a sphere or rect reads) against
 // the lane's ray.  best_prim receives the leaf's rt_prim index.
-// BOX: the tree may hold box leaves / media bounded by boxes (scenes without them skip that code altogether)
+// BOX: the tree may hold leaves other than static spheres and rects -- boxes, media, moving spheres (trees without them run
+// kernels compiled without that code: fewer registers, no spills in the node loop)
 template <bool BOX, class ST>
 RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, ST stack)
 {
@@ -235,26 +236,60 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
         h = (t >= t_min) & (t <= w.best_t) & (a >= __uint_as_float(la.x)) & (a <= __uint_as_float(la.y)) & (b >= __uint_as_float(la.z)) &
             (b <= __uint_as_float(la.w));
-    } else if (BOX && kind == RT_PRIM_GROUP) { // a box: one slab test for its six faces
+    } else if (!BOX) { // (a tree of spheres and rects only: the kernel is compiled without the rest)
+        h = false;
+    } else if (kind == RT_PRIM_GROUP) { // a box: one slab test for its six faces
         float tn, tf;
         const bool cut = box_range(v3(__uint_as_float(la.x), __uint_as_float(la.y), __uint_as_float(la.z)),
                                    v3(__uint_as_float(la.w), __uint_as_float(lb.x), __uint_as_float(lb.w)), lr, inv, tn, tf);
         t = tn >= t_min ? tn : tf;
         h = cut & (t >= t_min) & (t <= w.best_t);
-    } else { // moving sphere, constant_medium: the test reads the primitive itself
-        const rt_prim &pr = S.fprims[(int)lb.z];
-        if (kind == RT_PRIM_MEDIUM) { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment)
-            const rt_prim &bp = S.fprims[pr.first];
-            float t1 = 0.0f, t2 = 0.0f;
-            int dummy;
-            h = false;
-            bool both;
-            if (BOX && (bp.flags & RT_PRIM_IS_BOX)) { // the boundary's first hit on the whole line, then the first one after it
-                both = box_range(v3(bp.f[0], bp.f[1], bp.f[2]), v3(bp.f[3], bp.f[4], bp.f[5]), lr, inv, t1, t2) & (t2 > t1 + 0.0001f);
-            } else {
+    } else if (kind == RT_LEAF_MOVING_SPHERE) { // src/sphere.h:142-183, from the leaf's two slots (rt_bvh.h)
+        const uint4 le = q[2]; // c1 - c0
+        const float k = (lr.time - __uint_as_float(lb.x)) * __uint_as_float(lb.w); // center(time), src/sphere.h:142-145
+        const V3 c = v3(fmaf(k, __uint_as_float(le.x), __uint_as_float(la.x)), fmaf(k, __uint_as_float(le.y), __uint_as_float(la.y)),
+                        fmaf(k, __uint_as_float(le.z), __uint_as_float(la.z)));
+        const V3 oc = v3(lr.o.x - c.x, lr.o.y - c.y, lr.o.z - c.z);
+        float b, disc;
+        sphere_disc(oc, lr.d, w.dd, __uint_as_float(la.w), b, disc);
+        const float sq = fsqrt(disc);
+        const float t1 = (-b - sq) * w.inv_dd, t2 = (-b + sq) * w.inv_dd;
+        const bool in1 = (t1 < w.best_t) & (t1 > t_min), in2 = (t2 < w.best_t) & (t2 > t_min);
+        t = in1 ? t1 : t2;
+        h = (disc > 0.0f) & (in1 | in2);
+    } else { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment); or a primitive the leaf only names
+        // the boundary's first hit on the whole line, then the first one after it
+        float t1 = 0.0f, t2 = 0.0f, density = 1.0f;
+        int visits = 1;
+        bool both = false, medium = true;
+        if (kind == RT_LEAF_MEDIUM_SPHERE) { // sphere::hit twice: (-inf, inf) gives the smaller root, (t1 + 0.0001, inf) the larger
+            const V3 oc = v3(lr.o.x - __uint_as_float(la.x), lr.o.y - __uint_as_float(la.y), lr.o.z - __uint_as_float(la.z));
+            float b, disc;
+            sphere_disc(oc, lr.d, w.dd, __uint_as_float(la.w), b, disc);
+            const float sq = fsqrt(disc);
+            t1 = (-b - sq) * w.inv_dd, t2 = (-b + sq) * w.inv_dd;
+            both = (disc > 0.0f) & (t1 > -RT_FLT_MAX) & (t2 < RT_FLT_MAX) & (t2 > t1 + 0.0001f);
+            density = __uint_as_float(lb.x), visits = (int)lb.w;
+        } else if (kind == RT_LEAF_MEDIUM_BOX) {
+            const uint4 le = q[2], lf = q[3]; // density | ... visits
+            both = box_range(v3(__uint_as_float(la.x), __uint_as_float(la.y), __uint_as_float(la.z)),
+                             v3(__uint_as_float(la.w), __uint_as_float(lb.x), __uint_as_float(lb.w)), lr, inv, t1, t2) & (t2 > t1 + 0.0001f);
+            density = __uint_as_float(le.x), visits = (int)lf.w;
+        } else {
+            const rt_prim &pr = S.fprims[(int)lb.z];
+            medium = kind == RT_PRIM_MEDIUM;
+            if (medium) { // a boundary of another kind: its own hit function, twice
+                const rt_prim &bp = S.fprims[pr.first];
+                int dummy;
                 both = simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
                        simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy);
+                density = pr.f[0], visits = (int)lb.w;
+            } else {
+                h = plain_t(pr, lr, inv, w.dd, w.inv_dd, t_min, w.best_t, t);
             }
+        }
+        if (medium) {
+            h = false;
             if (both) {
                 t1 = fminf(fmaxf(t1, t_min), w.best_t);
                 if (t1 < t2) {
@@ -262,14 +297,12 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
                     // one draw per visit the reference pays this medium (rt_bvh.cpp: a lone child of a bvh_node is visited
                     // twice); the nearest of the candidates is what its tree keeps
                     float u = rng.next();
-                    for (int v = 1; v < (int)lb.w; ++v) u = fmaxf(u, rng.next());
-                    const float hit_distance = -rcp(pr.f[0]) * __logf(u);
+                    for (int v = 1; v < visits; ++v) u = fmaxf(u, rng.next());
+                    const float hit_distance = -rcp(density) * __logf(u);
                     t = fmaf(hit_distance, rsq(w.dd), t1);
                     h = true;
                 }
             }
-        } else {
-            h = plain_t(pr, lr, inv, w.dd, w.inv_dd, t_min, w.best_t, t);
         }
     }
     const bool take = h & (t <= w.best_t);
