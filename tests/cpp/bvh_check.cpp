@@ -53,7 +53,16 @@ static void walk(const rt_scene_desc *d, const std::vector<rt_bvh_node> &nodes, 
         if (!world_box(d, d->prims[lf.prim], b)) ++st.bad_box;
         for (int k = 0; k < 3; ++k)
             if (!(lo[k] <= b.lo[k] && b.hi[k] <= hi[k])) ++st.bad_box;
-        if ((int)(lf.kind_chain & 255u) != d->prims[lf.prim].kind) ++st.bad_box;
+        // the leaf's kind is the primitive's, or one of the self-contained forms of a medium / a moving sphere (rt_bvh.h);
+        // the forms of two slots are followed by a slot that no node refers to and that names the same primitive
+        const int lk = (int)(lf.kind_chain & 255u), pk = d->prims[lf.prim].kind;
+        const bool form_ok = lk == pk || ((lk == RT_LEAF_MEDIUM_SPHERE || lk == RT_LEAF_MEDIUM_BOX) && pk == RT_PRIM_MEDIUM) ||
+                             (lk == RT_LEAF_MOVING_SPHERE && pk == RT_PRIM_MOVING_SPHERE);
+        if (!form_ok) ++st.bad_box;
+        if (lk == RT_LEAF_MEDIUM_BOX || lk == RT_LEAF_MOVING_SPHERE) {
+            if ((size_t)(~ref) + 1 >= leaves.size() || leaves[~ref + 1].prim != lf.prim) ++st.bad_box;
+            ++st.leaves; // the second slot
+        }
         return;
     }
     ++st.nodes;
