@@ -1589,7 +1589,23 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
     int bvh_depth = 0;
     const bool lanes_ok = !fast_ok && rt_bvh_build(d, bvh, leaves, fprims, &bvh_depth) && rt_records_build_lights(d, &tab) != 0;
     if (!lanes_ok) bvh.clear(), leaves.clear(), fprims.clear();
-    part parts[14] = {
+    // per primitive of that table, what shading reads: material and texture folded into one record (rt_bvh.h)
+    std::vector<rt_shade_rec> fshade(fprims.size());
+    for (size_t i = 0; i < fprims.size(); ++i) {
+        rt_shade_rec &r = fshade[i];
+        memset(&r, 0, sizeof r);
+        r.texture = -1, r.color[0] = r.color[1] = r.color[2] = 1.0f;
+        const int mi = fprims[i].material;
+        if (mi < 0 || mi >= d->n_materials) continue; // a list: its members carry the materials
+        const rt_material &m = d->materials[mi];
+        r.mat_kind = (uint32_t)m.kind, r.p0 = m.p0;
+        if (m.texture >= 0) {
+            const rt_texture &tx = d->textures[m.texture];
+            if (tx.kind == RT_TEX_CONSTANT) r.color[0] = tx.color[0], r.color[1] = tx.color[1], r.color[2] = tx.color[2];
+            else r.texture = m.texture;
+        }
+    }
+    part parts[15] = {
         {d->entries, sizeof(rt_entry) * (size_t)d->n_entries, 0},
         {d->prims, sizeof(rt_prim) * (size_t)d->n_prims, 0},
         {d->xforms, sizeof(rt_xform) * (size_t)d->n_xforms, 0},
@@ -1604,6 +1620,7 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
         {bvh.data(), sizeof(rt_bvh_node) * bvh.size(), 0},
         {fprims.data(), sizeof(rt_prim) * fprims.size(), 0},
         {leaves.data(), sizeof(rt_leaf) * leaves.size(), 0},
+        {fshade.data(), sizeof(rt_shade_rec) * fshade.size(), 0},
     };
     size_t total = 0;
     for (part &p : parts) {
@@ -1648,6 +1665,7 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
     D.bvh = lanes_ok ? (const rt_bvh_node *)(b + parts[11].off) : nullptr;
     D.fprims = lanes_ok ? (const rt_prim *)(b + parts[12].off) : nullptr;
     D.leaves = lanes_ok ? (const rt_leaf *)(b + parts[13].off) : nullptr;
+    D.fshade = lanes_ok ? (const rt_shade_rec *)(b + parts[14].off) : nullptr;
     D.ordered = ordered ? 1 : 0;
     D.n_entries = d->n_entries, D.n_lights = d->n_lights;
     D.cam = d->camera;

@@ -63,6 +63,18 @@ typedef struct rt_leaf {
     int32_t  visits;     /* times the reference's tree visits this primitive (rt_bvh.cpp); box: the bits of p1.z */
 } rt_leaf;
 
+/* What shading needs about a primitive of that table, resolved on the host: the material and its texture in ONE 32-byte record
+ * indexed like the primitive table, fetched beside the primitive instead of after it (primitive -> material -> texture were
+ * three dependent fetches per shaded ray).  texture = -1: `color` is the material's constant colour; else an index into
+ * rt_scene_desc.textures (noise, checker, image) that shading evaluates. */
+typedef struct rt_shade_rec {
+    uint32_t mat_kind; /* rt_material_kind */
+    int32_t  texture;
+    float    p0;       /* fuzz / ref_idx */
+    float    color[3];
+    uint32_t pad[2];
+} rt_shade_rec;
+
 /* Builds the tree over the primitives the entry array names (each once; a list that is a box is one item, the members of
  * any other list are items of their own, so a leaf is one sphere, one rect, one box or one constant_medium).  `prims`
  * receives the primitive table rt_leaf.prim indexes: a copy of d->prims in which spheres under a rigid instance chain

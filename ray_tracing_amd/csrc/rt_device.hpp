@@ -105,6 +105,7 @@ struct DevScene {
     const ::rt_bvh_node *bvh; // rt_bvh.h
     const ::rt_leaf *leaves;  // that tree's leaves (rt_bvh.h), or null
     const rt_prim *fprims;    // the primitive table the leaves index (rt_bvh.h), or null: the fast per-lane path's own tree, or null
+    const ::rt_shade_rec *fshade; // [like fprims] material and texture of each primitive in one record (rt_bvh.h), or null
     const int2 *ord; // rt_order.h: per inner entry {right child, flags}; only read when ordered != 0
     int32_t n_entries, n_lights;
     int32_t ordered; // the entries are a binary tree no deeper than RT_ORD_MAX_DEPTH: world_hit_ordered may be used

@@ -386,16 +386,14 @@ RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int 
         }
     }
     s.n = n;
-    const rt_material m = S.materials[pr.material < 0 ? 0 : pr.material];
-    s.mat_kind = (uint32_t)m.kind;
-    s.p0 = m.p0;
-    s.texture = -1;
-    s.color = v3(1, 1, 1);
-    if (m.texture >= 0) {
-        const rt_texture &tx = S.textures[m.texture];
-        if (tx.kind == RT_TEX_CONSTANT) s.color = v3(tx.color[0], tx.color[1], tx.color[2]);
-        else s.texture = m.texture;
-    }
+    // material and texture, resolved on the host into one record per primitive (rt_bvh.h): for everything but a box it is
+    // fetched beside the primitive, not after it
+    const uint4 *sq = reinterpret_cast<const uint4 *>(S.fshade + s.face);
+    const uint4 sa = sq[0], sb = sq[1];
+    s.mat_kind = sa.x;
+    s.texture = (int32_t)sa.y;
+    s.p0 = __uint_as_float(sa.z);
+    s.color = v3(__uint_as_float(sa.w), __uint_as_float(sb.x), __uint_as_float(sb.y));
 }
 
 } // namespace rtf
