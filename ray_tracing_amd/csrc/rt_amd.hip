@@ -777,7 +777,7 @@ __device__ unsigned long long g_walk_counts[8];
 #ifdef RT_TIME_PHASES
 __device__ unsigned long long g_phase_cycles[4]; // [0] looks + shade + refill, [1] node steps, [2] leaf tests: wave cycles
 #endif
-template <bool TEX, bool BOX, int STEPS>
+template <bool TEX, int BOX, int STEPS> // BOX: 0 / 1 / 2 = the leaf kinds walk_leaf is compiled for
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 __attribute__((amdgpu_waves_per_eu(RT_LANES_WAVES_PER_EU, RT_LANES_WAVES_PER_EU)))
 void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
@@ -1077,7 +1077,7 @@ void render_fastlanes_block_kernel(DevScene S, const uint32_t *__restrict__ recs
             const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
             RT_COUNT(1, at_leaf);
             RT_COUNT_WAVE(5, __any(at_leaf));
-            if (at_leaf) rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack); // (a constant_medium draws, src/volume.h:43)
+            if (at_leaf) rtf::walk_leaf<(BOX ? 2 : 0)>(S, w, r, 0.001f, rng, stack); // (a constant_medium draws, src/volume.h:43)
         }
 
         // ---- regroup: walks that are over first (to be shaded), then the dead lanes (to be refilled), then the walks under way ----
@@ -1395,6 +1395,7 @@ struct rt_scene {
     bool fast_flat = false;     // the record stream holds no box records and is stored in runs
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     bool lanes_boxes = false;   // its tree holds leaves other than static spheres and rects: boxes (rt_box.h), media, moving spheres
+    int lanes_leaf_kinds = 0;   // 0: static spheres and rects only; 1: + moving spheres; 2: anything (render_fastlanes_kernel's BOX)
     int bvh_levels = 1;         // inner levels of that tree (rt_bvh_build)
     bool lanes_small = false;   // that tree has fewer than 32767 nodes and leaves: its references fit the 16-bit home stacks of render_fastlanes_block_kernel
     const char *fast_why = "";
@@ -1675,9 +1676,11 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
     s->lanes_ok = lanes_ok;
     s->bvh_levels = lanes_ok && bvh_depth > 0 ? bvh_depth : 1;
     s->lanes_small = lanes_ok && bvh.size() < 32767 && leaves.size() < 32767 && s->bvh_levels <= 31;
-    for (const rt_leaf &lf : leaves) { // anything but static spheres and rects: the kernels with the rest of walk_leaf
+    for (const rt_leaf &lf : leaves) { // anything but static spheres and rects: the kernels with (more of) the rest of walk_leaf
         const uint32_t k = lf.kind_chain & 255u;
-        s->lanes_boxes |= !(k == RT_PRIM_SPHERE || k == RT_PRIM_XY_RECT || k == RT_PRIM_XZ_RECT || k == RT_PRIM_YZ_RECT);
+        if (k == RT_PRIM_SPHERE || k == RT_PRIM_XY_RECT || k == RT_PRIM_XZ_RECT || k == RT_PRIM_YZ_RECT) continue;
+        s->lanes_boxes = true;
+        s->lanes_leaf_kinds = std::max(s->lanes_leaf_kinds, k == RT_LEAF_MOVING_SPHERE ? 1 : 2);
     }
     for (int m = 0; lanes_ok && m < d->n_materials; ++m)
         s->fast_textured |= d->materials[m].texture >= 0 && d->textures[d->materials[m].texture].kind != RT_TEX_CONSTANT;
@@ -1847,10 +1850,12 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     } while (0)
 #define RT_LAUNCH_LANES_STEPS(TEX, BOX) \
     do { if (steps == 4) RT_LAUNCH_LANES(TEX, BOX, 4); else RT_LAUNCH_LANES(TEX, BOX, 2); } while (0)
-        if (s->fast_textured && s->lanes_boxes) RT_LAUNCH_LANES_STEPS(true, true);
-        else if (s->fast_textured) RT_LAUNCH_LANES_STEPS(true, false);
-        else if (s->lanes_boxes) RT_LAUNCH_LANES_STEPS(false, true);
-        else RT_LAUNCH_LANES_STEPS(false, false);
+        if (s->fast_textured && s->lanes_leaf_kinds == 2) RT_LAUNCH_LANES_STEPS(true, 2);
+        else if (s->fast_textured && s->lanes_leaf_kinds == 1) RT_LAUNCH_LANES_STEPS(true, 1);
+        else if (s->fast_textured) RT_LAUNCH_LANES_STEPS(true, 0);
+        else if (s->lanes_leaf_kinds == 2) RT_LAUNCH_LANES_STEPS(false, 2);
+        else if (s->lanes_leaf_kinds == 1) RT_LAUNCH_LANES_STEPS(false, 1);
+        else RT_LAUNCH_LANES_STEPS(false, 0);
 #undef RT_LAUNCH_LANES_STEPS
 #undef RT_LAUNCH_LANES
     } else if (use_fast && block_kernel && chain) {

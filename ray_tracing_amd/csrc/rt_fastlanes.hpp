@@ -201,9 +201,9 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
 
 // lanes with cur < 0 (and not NONE): leaf ~cur (rt_bvh.h: 32 bytes, what the test of a sphere or rect reads) against
 // the lane's ray.  best_prim receives the leaf's rt_prim index.
-// BOX: the tree may hold leaves other than static spheres and rects -- boxes, media, moving spheres (trees without them run
-// kernels compiled without that code: fewer registers, no spills in the node loop)
-template <bool BOX, class ST>
+// BOX: which leaves the tree may hold besides static spheres and rects -- 0 none, 1 moving spheres, 2 anything (boxes, media).
+// Trees without them run kernels compiled without that code: fewer registers, no spills in the node loop.
+template <int BOX, class ST>
 RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, ST stack)
 {
     const uint4 *q = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.leaves) + ((uint32_t)~w.cur << 5));
@@ -236,14 +236,8 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
         h = (t >= t_min) & (t <= w.best_t) & (a >= __uint_as_float(la.x)) & (a <= __uint_as_float(la.y)) & (b >= __uint_as_float(la.z)) &
             (b <= __uint_as_float(la.w));
-    } else if (!BOX) { // (a tree of spheres and rects only: the kernel is compiled without the rest)
+    } else if (BOX == 0) { // (a tree of static spheres and rects only: the kernel is compiled without the rest)
         h = false;
-    } else if (kind == RT_PRIM_GROUP) { // a box: one slab test for its six faces
-        float tn, tf;
-        const bool cut = box_range(v3(__uint_as_float(la.x), __uint_as_float(la.y), __uint_as_float(la.z)),
-                                   v3(__uint_as_float(la.w), __uint_as_float(lb.x), __uint_as_float(lb.w)), lr, inv, tn, tf);
-        t = tn >= t_min ? tn : tf;
-        h = cut & (t >= t_min) & (t <= w.best_t);
     } else if (kind == RT_LEAF_MOVING_SPHERE) { // src/sphere.h:142-183, from the leaf's two slots (rt_bvh.h)
         const uint4 le = q[2]; // c1 - c0
         const float k = (lr.time - __uint_as_float(lb.x)) * __uint_as_float(lb.w); // center(time), src/sphere.h:142-145
@@ -257,6 +251,14 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         const bool in1 = (t1 < w.best_t) & (t1 > t_min), in2 = (t2 < w.best_t) & (t2 > t_min);
         t = in1 ? t1 : t2;
         h = (disc > 0.0f) & (in1 | in2);
+    } else if (BOX < 2) { // (no boxes or media in the tree: the kernel is compiled without them)
+        h = false;
+    } else if (kind == RT_PRIM_GROUP) { // a box: one slab test for its six faces
+        float tn, tf;
+        const bool cut = box_range(v3(__uint_as_float(la.x), __uint_as_float(la.y), __uint_as_float(la.z)),
+                                   v3(__uint_as_float(la.w), __uint_as_float(lb.x), __uint_as_float(lb.w)), lr, inv, tn, tf);
+        t = tn >= t_min ? tn : tf;
+        h = cut & (t >= t_min) & (t <= w.best_t);
     } else { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment); or a primitive the leaf only names
         // the boundary's first hit on the whole line, then the first one after it
         float t1 = 0.0f, t2 = 0.0f, density = 1.0f;
@@ -319,7 +321,7 @@ RTF_DEV bool hit_bvh(const DevScene &S, const Ray &wr, float t_min, float t_max,
     walk_start(w, wr, t_max, alive);
     while (__any(w.cur != RT_BVH_NONE)) {
         while (w.cur >= 0) walk_node(S, w, t_min, stack);
-        if (w.cur != RT_BVH_NONE) walk_leaf<true>(S, w, wr, t_min, rng, stack);
+        if (w.cur != RT_BVH_NONE) walk_leaf<2>(S, w, wr, t_min, rng, stack);
     }
     best_t = w.best_t, best_prim = w.best_prim;
     return best_prim >= 0;
