@@ -775,7 +775,7 @@ __device__ unsigned long long g_walk_counts[8];
 #define RT_COUNT_WAVE(k, any)
 #endif
 #ifdef RT_TIME_PHASES
-__device__ unsigned long long g_phase_cycles[4]; // [0] looks + shade + refill, [1] node steps, [2] leaf tests: wave cycles
+__device__ unsigned long long g_phase_cycles[8]; // wave cycles in [0] looks + refill + task hand-over, [1] node steps, [2] leaf tests, [3] surface, [4] shade
 #endif
 template <bool TEX, int BOX, int STEPS> // BOX: 0 / 1 / 2 = the leaf kinds walk_leaf is compiled for
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
@@ -826,7 +826,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
 #endif
 
 #ifdef RT_TIME_PHASES // development (tools/phase_times.py): cycles a wave spends in each phase of the loop
-    unsigned long long tp[4] = {0ull, 0ull, 0ull, 0ull}, tp_mark = clock64();
+    unsigned long long tp[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, tp_mark = clock64();
 #define RT_PHASE(k) do { const unsigned long long now_ = clock64(); tp[k] += now_ - tp_mark; tp_mark = now_; } while (0)
 #else
 #define RT_PHASE(k)
@@ -843,9 +843,13 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                 const bool hit_any = w.best_prim >= 0;
                 rtf::Surface sf;
                 sf.p = r.o; // a miss ends the path; shade still writes the (dead) ray from it
+                RT_PHASE(0);
                 if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
+                RT_PHASE(3);
                 V3 L;
-                if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
+                const bool goes_on = rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L);
+                RT_PHASE(4);
+                if (!goes_on) {
                     alive = false;
                     const uint32_t pw = rng.w;
                     const int pix = (int)(((pw >> 16) & 7u) * 8u + (pw & 7u));
@@ -934,7 +938,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
 #ifdef RT_TIME_PHASES
     if (lane == 0)
-        for (int k = 0; k < 3; ++k) atomicAdd(&g_phase_cycles[k], tp[k]);
+        for (int k = 0; k < 5; ++k) atomicAdd(&g_phase_cycles[k], tp[k]);
 #endif
 #undef RT_PHASE
 #ifdef RT_COUNT_WALK
@@ -2129,13 +2133,13 @@ extern "C" int rt_debug_walk_counts(unsigned long long *out8, int reset)
 
 #ifdef RT_TIME_PHASES
 // development builds only (tools/phase_times.py): wave cycles per phase of render_fastlanes_kernel since the last reset
-extern "C" int rt_debug_phase_cycles(unsigned long long *out4, int reset)
+extern "C" int rt_debug_phase_cycles(unsigned long long *out4, int reset) // out4: eight counters
 {
     void *p = nullptr;
     RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_cycles)));
     RT_HIP(hipDeviceSynchronize());
-    if (out4) RT_HIP(hipMemcpy(out4, p, 32, hipMemcpyDeviceToHost));
-    if (reset) RT_HIP(hipMemset(p, 0, 32));
+    if (out4) RT_HIP(hipMemcpy(out4, p, 64, hipMemcpyDeviceToHost));
+    if (reset) RT_HIP(hipMemset(p, 0, 64));
     return RT_OK;
 }
 #endif

@@ -374,8 +374,8 @@ bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::
         const Node32 &n = tree[i];
         rt_bvh_node &o = nodes[i];
         for (int k = 0; k < 3; ++k) {
-            o.lo0[k] = to_half(n.lo0[k], false), o.hi0[k] = to_half(n.hi0[k], true);
-            o.lo1[k] = to_half(n.lo1[k], false), o.hi1[k] = to_half(n.hi1[k], true);
+            o.box0[k][0] = to_half(n.lo0[k], false), o.box0[k][1] = to_half(n.hi0[k], true);
+            o.box1[k][0] = to_half(n.lo1[k], false), o.box1[k][1] = to_half(n.hi1[k], true);
         }
         o.ref0 = leaf_of(n.ref0), o.ref1 = leaf_of(n.ref1);
     }

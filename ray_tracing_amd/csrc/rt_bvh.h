@@ -31,12 +31,14 @@
 
 /* Inner node, 32 bytes (two dwordx4 loads from one cache line): the boxes of both children as IEEE half floats, rounded
  * outwards (lo down, hi up; beyond the half range they become -inf / +inf), and the two child references.  The walk
- * feeds the halves straight into v_fma_mix_f32 (t = half(lo) * (1/d) - o/d in one instruction), so the halved node
- * costs no decoding.  A box that is a little too large only costs a visit. */
+ * feeds the halves straight into v_fma_mix_f32 (t = half(plane) * (1/d) - o/d in one instruction), so the halved node
+ * costs no decoding.  The two planes of an axis share a dword, lo in the low half: rotated by 16 bits when the ray's
+ * direction is negative on that axis (one v_alignbit with a per-ray amount), the low half is the plane the ray meets first,
+ * so entry and exit distances need no min / max per axis.  A box that is a little too large only costs a visit. */
 typedef struct rt_bvh_node {
-    uint16_t lo0[3], hi0[3];
+    uint16_t box0[3][2]; /* [axis]{lo, hi} */
     int32_t  ref0;
-    uint16_t lo1[3], hi1[3];
+    uint16_t box1[3][2];
     int32_t  ref1;
 } rt_bvh_node;
 

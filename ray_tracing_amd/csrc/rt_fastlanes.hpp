@@ -122,15 +122,15 @@ struct Walk {
     int best_prim; // a MEDIUM primitive for a hit inside a constant_medium
     V3 winv, noi;  // 1/d and -o/d: t = lo * winv + noi, one FMA per plane.  Where 1/d overflows the two terms can
                    // cancel to NaN; min/max drop a NaN, which only ever makes a box easier to enter.
-    float dd, inv_dd; // d.d (chains are rigid: the same in every space)
+    uint32_t rx, ry, rz; // 16 where the direction is negative on that axis, else 0: how far walk_node rotates a node's plane
+                         // pairs so that the plane met first is in the low half (rt_bvh.h)
 };
 // what a walk keeps about its ray (also made again when a walk under way moves to another lane)
 RTF_DEV void walk_ray_constants(Walk &w, const Ray &wr)
 {
     w.winv = rcp3(wr.d);
     w.noi = v3(-wr.o.x * w.winv.x, -wr.o.y * w.winv.y, -wr.o.z * w.winv.z);
-    w.dd = ref_dot(wr.d, wr.d);
-    w.inv_dd = rcp(w.dd);
+    w.rx = (__float_as_uint(w.winv.x) >> 31) << 4, w.ry = (__float_as_uint(w.winv.y) >> 31) << 4, w.rz = (__float_as_uint(w.winv.z) >> 31) << 4;
 }
 RTF_DEV void walk_start(Walk &w, const Ray &wr, float t_max, bool go)
 {
@@ -138,10 +138,7 @@ RTF_DEV void walk_start(Walk &w, const Ray &wr, float t_max, bool go)
     w.sp = 0;
     w.best_t = t_max;
     w.best_prim = -1;
-    w.winv = rcp3(wr.d);
-    w.noi = v3(-wr.o.x * w.winv.x, -wr.o.y * w.winv.y, -wr.o.z * w.winv.z);
-    w.dd = ref_dot(wr.d, wr.d); // as src/sphere.h:27 rounds it: it enters the sign of the discriminant (sphere_disc)
-    w.inv_dd = rcp(w.dd);
+    walk_ray_constants(w, wr);
 }
 // Where a lane keeps its pending children.  The walk only pushes and pops, so the stack is a policy:
 //   int *                one dword per level, [level][lane] of the lane's wave (the lane's place in its wave never changes)
@@ -171,16 +168,16 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
     // (a 32-bit byte offset from the table's base: the load takes the base from scalar registers, the lane computes one shift;
     // trees are far below 4 GiB -- 4M primitives are 256 MiB)
     const uint4 *q = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.bvh) + ((uint32_t)w.cur << 5));
-    const uint4 a = q[0], b = q[1]; // {lo.x|lo.y, lo.z|hi.x, hi.y|hi.z, ref} per child
+    const uint4 a = q[0], b = q[1]; // {x lo|hi, y lo|hi, z lo|hi, ref} per child
     const V3 i = w.winv, n = w.noi;
-    const float x00 = plane_lo(a.x, i.x, n.x), y00 = plane_hi(a.x, i.y, n.y), z00 = plane_lo(a.y, i.z, n.z);
-    const float x01 = plane_hi(a.y, i.x, n.x), y01 = plane_lo(a.z, i.y, n.y), z01 = plane_hi(a.z, i.z, n.z);
-    const float x10 = plane_lo(b.x, i.x, n.x), y10 = plane_hi(b.x, i.y, n.y), z10 = plane_lo(b.y, i.z, n.z);
-    const float x11 = plane_hi(b.y, i.x, n.x), y11 = plane_lo(b.z, i.y, n.y), z11 = plane_hi(b.z, i.z, n.z);
-    const float tn0 = fmaxf(fmax3(fminf(x00, x01), fminf(y00, y01), fminf(z00, z01)), t_min);
-    const float tf0 = fminf(fmin3(fmaxf(x00, x01), fmaxf(y00, y01), fmaxf(z00, z01)), w.best_t);
-    const float tn1 = fmaxf(fmax3(fminf(x10, x11), fminf(y10, y11), fminf(z10, z11)), t_min);
-    const float tf1 = fminf(fmin3(fmaxf(x10, x11), fmaxf(y10, y11), fmaxf(z10, z11)), w.best_t);
+    // the plane the ray meets first into the low half of each pair; then entry = max of the three near planes, exit = min of
+    // the three far ones (a NaN -- a plane through the origin of a ray parallel to it -- is dropped by max3 / min3)
+    const uint32_t ax = __builtin_amdgcn_alignbit(a.x, a.x, w.rx), ay = __builtin_amdgcn_alignbit(a.y, a.y, w.ry), az = __builtin_amdgcn_alignbit(a.z, a.z, w.rz);
+    const uint32_t bx = __builtin_amdgcn_alignbit(b.x, b.x, w.rx), by = __builtin_amdgcn_alignbit(b.y, b.y, w.ry), bz = __builtin_amdgcn_alignbit(b.z, b.z, w.rz);
+    const float tn0 = fmaxf(fmax3(plane_lo(ax, i.x, n.x), plane_lo(ay, i.y, n.y), plane_lo(az, i.z, n.z)), t_min);
+    const float tf0 = fminf(fmin3(plane_hi(ax, i.x, n.x), plane_hi(ay, i.y, n.y), plane_hi(az, i.z, n.z)), w.best_t);
+    const float tn1 = fmaxf(fmax3(plane_lo(bx, i.x, n.x), plane_lo(by, i.y, n.y), plane_lo(bz, i.z, n.z)), t_min);
+    const float tf1 = fminf(fmin3(plane_hi(bx, i.x, n.x), plane_hi(by, i.y, n.y), plane_hi(bz, i.z, n.z)), w.best_t);
     const int ref0 = (int)a.w, ref1 = (int)b.w;
     const bool h0 = tf0 >= tn0, h1 = (tf1 >= tn1) & (ref1 != RT_BVH_NONE);
     // "First" is the box to open now: the only one that was hit, or of two the nearer.  It is to be opened if either was hit
@@ -209,6 +206,9 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
     const uint4 *q = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.leaves) + ((uint32_t)~w.cur << 5));
     const uint4 la = q[0], lb = q[1]; // f0 f1 f2 f3 | f4 kind_chain prim visits
     const int kind = (int)(lb.y & 255u), chain = (int)(lb.y >> 8);
+    // d.d as src/sphere.h:27 rounds it (it enters the sign of the discriminant, sphere_disc) and its reciprocal: made here, per
+    // leaf test, rather than carried through the walk in two registers (chains are rigid: the same in every space)
+    const float w_dd = ref_dot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
     Ray lr = wr;
     V3 inv = w.winv;
     if (chain != 0) {
@@ -221,9 +221,9 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         const V3 oc = v3(lr.o.x - __uint_as_float(la.x), lr.o.y - __uint_as_float(la.y), lr.o.z - __uint_as_float(la.z));
         const float radius = __uint_as_float(la.w);
         float b, disc;
-        sphere_disc(oc, lr.d, w.dd, radius, b, disc);
+        sphere_disc(oc, lr.d, w_dd, radius, b, disc);
         const float sq = fsqrt(disc);
-        const float t1 = (-b - sq) * w.inv_dd, t2 = (-b + sq) * w.inv_dd;
+        const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
         const bool in1 = (t1 < w.best_t) & (t1 > t_min), in2 = (t2 < w.best_t) & (t2 > t_min);
         t = in1 ? t1 : t2;
         h = (disc > 0.0f) & (in1 | in2);
@@ -245,9 +245,9 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
                         fmaf(k, __uint_as_float(le.z), __uint_as_float(la.z)));
         const V3 oc = v3(lr.o.x - c.x, lr.o.y - c.y, lr.o.z - c.z);
         float b, disc;
-        sphere_disc(oc, lr.d, w.dd, __uint_as_float(la.w), b, disc);
+        sphere_disc(oc, lr.d, w_dd, __uint_as_float(la.w), b, disc);
         const float sq = fsqrt(disc);
-        const float t1 = (-b - sq) * w.inv_dd, t2 = (-b + sq) * w.inv_dd;
+        const float t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
         const bool in1 = (t1 < w.best_t) & (t1 > t_min), in2 = (t2 < w.best_t) & (t2 > t_min);
         t = in1 ? t1 : t2;
         h = (disc > 0.0f) & (in1 | in2);
@@ -267,9 +267,9 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         if (kind == RT_LEAF_MEDIUM_SPHERE) { // sphere::hit twice: (-inf, inf) gives the smaller root, (t1 + 0.0001, inf) the larger
             const V3 oc = v3(lr.o.x - __uint_as_float(la.x), lr.o.y - __uint_as_float(la.y), lr.o.z - __uint_as_float(la.z));
             float b, disc;
-            sphere_disc(oc, lr.d, w.dd, __uint_as_float(la.w), b, disc);
+            sphere_disc(oc, lr.d, w_dd, __uint_as_float(la.w), b, disc);
             const float sq = fsqrt(disc);
-            t1 = (-b - sq) * w.inv_dd, t2 = (-b + sq) * w.inv_dd;
+            t1 = (-b - sq) * w_inv_dd, t2 = (-b + sq) * w_inv_dd;
             both = (disc > 0.0f) & (t1 > -RT_FLT_MAX) & (t2 < RT_FLT_MAX) & (t2 > t1 + 0.0001f);
             density = __uint_as_float(lb.x), visits = (int)lb.w;
         } else if (kind == RT_LEAF_MEDIUM_BOX) {
@@ -283,11 +283,11 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
             if (medium) { // a boundary of another kind: its own hit function, twice
                 const rt_prim &bp = S.fprims[pr.first];
                 int dummy;
-                both = simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
-                       simple_t(S, pr.first, bp, lr, inv, w.dd, w.inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy);
+                both = simple_t(S, pr.first, bp, lr, inv, w_dd, w_inv_dd, -RT_FLT_MAX, RT_FLT_MAX, t1, dummy) &&
+                       simple_t(S, pr.first, bp, lr, inv, w_dd, w_inv_dd, t1 + 0.0001f, RT_FLT_MAX, t2, dummy);
                 density = pr.f[0], visits = (int)lb.w;
             } else {
-                h = plain_t(pr, lr, inv, w.dd, w.inv_dd, t_min, w.best_t, t);
+                h = plain_t(pr, lr, inv, w_dd, w_inv_dd, t_min, w.best_t, t);
             }
         }
         if (medium) {
@@ -301,7 +301,7 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
                     float u = rng.next();
                     for (int v = 1; v < visits; ++v) u = fmaxf(u, rng.next());
                     const float hit_distance = -rcp(density) * __logf(u);
-                    t = fmaf(hit_distance, rsq(w.dd), t1);
+                    t = fmaf(hit_distance, rsq(w_dd), t1);
                     h = true;
                 }
             }

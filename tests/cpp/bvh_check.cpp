@@ -69,7 +69,7 @@ static void walk(const rt_scene_desc *d, const std::vector<rt_bvh_node> &nodes, 
     const rt_bvh_node &n = nodes[ref];
     float l0[3], h0[3], l1[3], h1[3];
     for (int k = 0; k < 3; ++k) {
-        l0[k] = half_value(n.lo0[k]), h0[k] = half_value(n.hi0[k]), l1[k] = half_value(n.lo1[k]), h1[k] = half_value(n.hi1[k]);
+        l0[k] = half_value(n.box0[k][0]), h0[k] = half_value(n.box0[k][1]), l1[k] = half_value(n.box1[k][0]), h1[k] = half_value(n.box1[k][1]);
         // children inside the parent (the root's parent is everything)
         if (!(lo[k] <= l0[k] && h0[k] <= hi[k])) ++st.bad_box;
         if (n.ref1 != RT_BVH_NONE && !(lo[k] <= l1[k] && h1[k] <= hi[k])) ++st.bad_box;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the waves of render_fastlanes_kernel spend their time: wave cycles in (looks + shade + refill) / node steps / leaf tests
+"""Where the waves of render_fastlanes_kernel spend their time: wave cycles in looks + refill / surface / shade / node steps / leaf tests
 (needs a library built with -DRT_TIME_PHASES: tools/build_variant.sh phases -DRT_TIME_PHASES, then
 RT_AMD_LIB=ray_tracing_amd/build_var/librt_phases.so).  usage: phase_times.py [--opt NAME=VALUE ...] scene:nx:ny:spp ..."""
 import ctypes as C, os, sys
@@ -25,9 +25,10 @@ for job in jobs:
     lib.rt_debug_phase_cycles(None, 1)
     api.render(sc, acc, nx, ny, 0, spp)
     torch.cuda.synchronize()
-    out = (C.c_ulonglong * 4)()
+    out = (C.c_ulonglong * 8)()
     lib.rt_debug_phase_cycles(out, 1)
-    t = [int(x) for x in out][:3]
+    t = [int(x) for x in out][:5]
     tot = sum(t) or 1
-    print(f"{name} {nx}x{ny}x{spp}: looks+shade+refill {100 * t[0] / tot:.1f} %, node steps {100 * t[1] / tot:.1f} %, leaf tests {100 * t[2] / tot:.1f} % of the waves' time ({sc.last_render_ms():.2f} ms)", flush=True)
+    print(f"{name} {nx}x{ny}x{spp}: looks+refill+hand-over {100 * t[0] / tot:.1f} %, surface {100 * t[3] / tot:.1f} %, shade {100 * t[4] / tot:.1f} %, "
+          f"node steps {100 * t[1] / tot:.1f} %, leaf tests {100 * t[2] / tot:.1f} % of the waves' time ({sc.last_render_ms():.2f} ms)", flush=True)
     sc.close()
