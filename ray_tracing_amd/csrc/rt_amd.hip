@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 // leaf wait until RT_LEAF_BATCH of them do (or nobody is opening nodes).  This keeps the lanes of a wave busy although
 // every ray takes its own number of steps through the tree.
 #ifndef RT_SHADE_BATCH
-#define RT_SHADE_BATCH 40
+#define RT_SHADE_BATCH 48
 #endif
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 16
@@ -948,7 +948,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
 
 // ---------------------------------------------------------------------------
 // render_fastlanes_block_kernel: the per-lane walk with the paths of a BLOCK regrouped every few node steps.
-// In render_fastlanes_kernel a lane whose walk is over waits, in its wave, until forty lanes do; a node step therefore
+// In render_fastlanes_kernel a lane whose walk is over waits, in its wave, until forty-eight lanes do; a node step therefore
 // runs with 30 - 39 of a wave's 64 lanes on.  Here the four waves of a block trade paths through LDS after every round of
 // a few node steps and leaf tests -- finished walks first, then dead lanes, then the walks still under way -- so the
 // finished walks of all four waves are shaded together by whole waves, the dead lanes are refilled together, and the
@@ -1834,9 +1834,14 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
         A.leaf_batch = s->opt_leaf_batch > 0 ? s->opt_leaf_batch : RT_LEAF_BATCH;
         int steps = s->bvh_levels > 20 ? 4 : 2;
         // deep trees: shade and test leaves in smaller batches (a lane that waits is a lane that does not walk, and walks are
-        // long there); tools/batch_sweep.py: 1M spheres 1203 -> 1278 Mpaths/s at (32, 4), the others are at their best near (40, 16)
+        // long there); tools/batch_sweep.py, swept again after the round-3 walk (a node step costs less now, so waiting for a
+        // fuller shade costs less): 1M spheres is at its best at (40, 4) -- 1776 against 1738 Mpaths/s at (32, 4) -- and the others near
+        // (48, 16): random spheres 8786 against 8640 at (40, 16), smoke-box Cornell 9031 against 8534, Next-Week final 2314 against 2290
+        // a tree of static spheres and rects only has a cheap leaf test, and waiting for a batch of it pays less: 4096 spheres
+        // 2603 -> 2813 Mpaths/s at (48, 8)
+        if (s->lanes_leaf_kinds == 0 && s->opt_leaf_batch <= 0) A.leaf_batch = 8;
         if (s->bvh_levels > 20) {
-            if (s->opt_shade_batch <= 0) A.shade_batch = 32;
+            if (s->opt_shade_batch <= 0) A.shade_batch = 40;
             if (s->opt_leaf_batch <= 0) A.leaf_batch = 4;
         }
         if (s->opt_node_steps == 2 || s->opt_node_steps == 4) steps = s->opt_node_steps; // RT_OPT_NODE_STEPS
