@@ -756,6 +756,11 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 16
 #endif
+// Up to this many lanes of a shade phase that ask for a noise texture are served one by one by the whole wave
+// (rtf::wave_noise_value); more, and every lane evaluates its own (0 in a build: never).
+#ifndef RT_WAVE_NOISE_MAX
+#define RT_WAVE_NOISE_MAX 16
+#endif
 // Node steps between two looks at who waits for a leaf test or for shading (template parameter STEPS; the looks cost a fifth
 // of a node step).  1 / 2 / 3 / 4 steps: random spheres 6.1 / 6.4 / 6.3 / 6.2, Next-Week final 1.63 / 1.75 / 1.75 / 1.66, 1M spheres
 // 1.04 / 1.09 / 1.15 / 1.18 Gpaths/s: two, and four for deep trees.
@@ -777,7 +782,8 @@ __device__ unsigned long long g_walk_counts[8];
 #ifdef RT_TIME_PHASES
 __device__ unsigned long long g_phase_cycles[8]; // wave cycles in [0] looks + refill + task hand-over, [1] node steps, [2] leaf tests, [3] surface, [4] shade
 #endif
-template <bool TEX, int BOX, int STEPS> // BOX: 0 / 1 / 2 = the leaf kinds walk_leaf is compiled for
+template <int TEX, int BOX, int STEPS> // TEX: 0 constant colours only, 1 textures, 2 textures, a noise texture among them (with BOX = 2);
+                                        // BOX: 0 / 1 / 2 = the leaf kinds walk_leaf is compiled for
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 __attribute__((amdgpu_waves_per_eu(RT_LANES_WAVES_PER_EU, RT_LANES_WAVES_PER_EU)))
 void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
@@ -839,15 +845,35 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
         if (n_waiting >= A.shade_batch || !walking_any) {
             RT_COUNT_WAVE(6, n_waiting > 0);
             RT_COUNT(7, waiting);
+            float noise_c = -1.0f;
+            if (TEX == 2) {
+                // Noise textures, while few lanes ask: the whole wave evaluates one lane's point (rtf::wave_noise_value: 60
+                // instructions per point instead of 1400 for the wave), and that lane goes on with a constant colour.  That a lane
+                // will ask is a flag on its best hit (RT_LEAF_PRIM_NOISE, rt_bvh.h: no fetch decides it; a box's faces, which are
+                // named later, evaluate their own).
+                unsigned long long ask = __ballot(waiting & (w.best_prim >= 0) & ((w.best_prim & RT_LEAF_PRIM_NOISE) != 0));
+                if (ask != 0ull && __popcll(ask) <= RT_WAVE_NOISE_MAX) {
+                    const V3 hp = rtf::fma3(w.best_t, r.d, r.o);
+                    do {
+                        const int src = __ffsll((long long)ask) - 1;
+                        const int prim_s = (int)rtf::rl_u((uint32_t)w.best_prim, src) & RT_LEAF_PRIM_MASK;
+                        const float c = rtf::wave_noise_value(S.fshade[prim_s].tex_scale, rtf::rl_f(__float_as_uint(hp.x), src),
+                                                              rtf::rl_f(__float_as_uint(hp.y), src), rtf::rl_f(__float_as_uint(hp.z), src), lane);
+                        noise_c = lane == src ? c : noise_c;
+                        ask &= ask - 1ull;
+                    } while (ask != 0ull);
+                }
+            }
             if (waiting) {
                 const bool hit_any = w.best_prim >= 0;
                 rtf::Surface sf;
                 sf.p = r.o; // a miss ends the path; shade still writes the (dead) ray from it
                 RT_PHASE(0);
                 if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
+                if (TEX == 2 && noise_c >= 0.0f) sf.color = v3(noise_c, noise_c, noise_c), sf.texture = -1;
                 RT_PHASE(3);
                 V3 L;
-                const bool goes_on = rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L);
+                const bool goes_on = rtf::shade<TEX != 0>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L);
                 RT_PHASE(4);
                 if (!goes_on) {
                     alive = false;
@@ -1298,6 +1324,26 @@ __global__ __launch_bounds__(256) void debug_eval_kernel(DevScene S, const uint3
     for (int k = 0; k < 16; ++k) out[k] = o16[k];
 }
 
+// RT_EVAL_TEXTURE, second pass: out[6] = rtf::wave_noise_value of the item's point where its texture is a noise texture (what
+// the per-lane render kernel calls when few lanes of a shade phase ask).  Whole waves: lanes past n stay and take part.
+__global__ __launch_bounds__(256) void debug_wave_noise_kernel(DevScene S, int n, const float *__restrict__ in_all, float *__restrict__ out_all)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const float *in = in_all + 16 * (size_t)(i < n ? i : 0);
+    const V3 p = v3(in[3], in[4], in[5]);
+    const rt_texture t = S.textures[(int)in[0]];
+    unsigned long long ask = __ballot((i < n) & (t.kind == RT_TEX_NOISE));
+    float mine = 0.0f;
+    while (ask != 0ull) {
+        const int src = __ffsll((long long)ask) - 1;
+        const float c = rtf::wave_noise_value(rtf::rl_f(__float_as_uint(t.scale), src), rtf::rl_f(__float_as_uint(p.x), src),
+                                              rtf::rl_f(__float_as_uint(p.y), src), rtf::rl_f(__float_as_uint(p.z), src), lane);
+        mine = lane == src ? c : mine;
+        ask &= ask - 1ull;
+    }
+    if (i < n) out_all[16 * (size_t)i + 6] = mine;
+}
+
 // RT_EVAL_BOUNCE: world->hit() and ONE bounce of color() for the ray in[0..6] on the stream (key, pixel) = in[7], in[8].
 // out: hit (0/1), material kind, continues (0/1), scattered direction, throughput factor (T = 1 before the bounce; a path that
 // ends reports its radiance there), t.   EXACT family: the kernels of RT_PATH_EXACT.
@@ -1396,6 +1442,7 @@ struct rt_scene {
     // register-resident form (rt_records.h), when the scene fits
     bool fast_ok = false;
     bool fast_textured = false; // some material's texture is not a constant
+    bool lanes_noise = false;   // per-lane tree: some leaf carries RT_LEAF_PRIM_NOISE (render_fastlanes_kernel's TEX = 2)
     bool fast_flat = false;     // the record stream holds no box records and is stored in runs
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     bool lanes_boxes = false;   // its tree holds leaves other than static spheres and rects: boxes (rt_box.h), media, moving spheres
@@ -1607,7 +1654,7 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
         if (m.texture >= 0) {
             const rt_texture &tx = d->textures[m.texture];
             if (tx.kind == RT_TEX_CONSTANT) r.color[0] = tx.color[0], r.color[1] = tx.color[1], r.color[2] = tx.color[2];
-            else r.texture = m.texture;
+            else r.texture = m.texture, r.tex_kind = (uint32_t)tx.kind, r.tex_scale = tx.scale;
         }
     }
     part parts[15] = {
@@ -1681,6 +1728,7 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
     s->bvh_levels = lanes_ok && bvh_depth > 0 ? bvh_depth : 1;
     s->lanes_small = lanes_ok && bvh.size() < 32767 && leaves.size() < 32767 && s->bvh_levels <= 31;
     for (const rt_leaf &lf : leaves) { // anything but static spheres and rects: the kernels with (more of) the rest of walk_leaf
+        s->lanes_noise |= (lf.prim & RT_LEAF_PRIM_NOISE) != 0;
         const uint32_t k = lf.kind_chain & 255u;
         if (k == RT_PRIM_SPHERE || k == RT_PRIM_XY_RECT || k == RT_PRIM_XZ_RECT || k == RT_PRIM_YZ_RECT) continue;
         s->lanes_boxes = true;
@@ -1859,12 +1907,13 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     } while (0)
 #define RT_LAUNCH_LANES_STEPS(TEX, BOX) \
     do { if (steps == 4) RT_LAUNCH_LANES(TEX, BOX, 4); else RT_LAUNCH_LANES(TEX, BOX, 2); } while (0)
-        if (s->fast_textured && s->lanes_leaf_kinds == 2) RT_LAUNCH_LANES_STEPS(true, 2);
-        else if (s->fast_textured && s->lanes_leaf_kinds == 1) RT_LAUNCH_LANES_STEPS(true, 1);
-        else if (s->fast_textured) RT_LAUNCH_LANES_STEPS(true, 0);
-        else if (s->lanes_leaf_kinds == 2) RT_LAUNCH_LANES_STEPS(false, 2);
-        else if (s->lanes_leaf_kinds == 1) RT_LAUNCH_LANES_STEPS(false, 1);
-        else RT_LAUNCH_LANES_STEPS(false, 0);
+        if (s->lanes_noise) RT_LAUNCH_LANES_STEPS(2, 2); // (the kernel for any leaf kind, whatever the tree's)
+        else if (s->fast_textured && s->lanes_leaf_kinds == 2) RT_LAUNCH_LANES_STEPS(1, 2);
+        else if (s->fast_textured && s->lanes_leaf_kinds == 1) RT_LAUNCH_LANES_STEPS(1, 1);
+        else if (s->fast_textured) RT_LAUNCH_LANES_STEPS(1, 0);
+        else if (s->lanes_leaf_kinds == 2) RT_LAUNCH_LANES_STEPS(0, 2);
+        else if (s->lanes_leaf_kinds == 1) RT_LAUNCH_LANES_STEPS(0, 1);
+        else RT_LAUNCH_LANES_STEPS(0, 0);
 #undef RT_LAUNCH_LANES_STEPS
 #undef RT_LAUNCH_LANES
     } else if (use_fast && block_kernel && chain) {
@@ -2074,6 +2123,7 @@ extern "C" int rt_debug_eval(rt_scene *s, int kind, int32_t n, const float *h_in
                 hipLaunchKernelGGL(debug_bounce_fast_kernel<false>, g, b, 0, nullptr, s->dev, s->d_records, s->layout, n, d_in, d_out);
         } else {
             hipLaunchKernelGGL(debug_eval_kernel, g, b, 0, nullptr, s->dev, s->d_records, s->layout, kind, n, d_in, d_out);
+            if (kind == RT_EVAL_TEXTURE) hipLaunchKernelGGL(debug_wave_noise_kernel, g, b, 0, nullptr, s->dev, n, d_in, d_out);
         }
         e = hipGetLastError();
     }

@@ -341,6 +341,11 @@ bool rt_bvh_build(const rt_scene_desc *d, std::vector<rt_bvh_node> &nodes, std::
         for (int k = 0; k < 5; ++k) lf.f[k] = p.kind == RT_PRIM_MEDIUM ? 0.0f : p.f[k];
         lf.kind_chain = (uint32_t)p.kind | ((uint32_t)shape.chain << 8);
         lf.prim = pi;
+        if ((p.kind <= RT_PRIM_MOVING_SPHERE || p.kind == RT_PRIM_XY_RECT || p.kind == RT_PRIM_XZ_RECT || p.kind == RT_PRIM_YZ_RECT) &&
+            p.material >= 0 && p.material < d->n_materials) {
+            const int32_t tx = d->materials[p.material].texture;
+            if (tx >= 0 && tx < d->n_textures && d->textures[tx].kind == RT_TEX_NOISE) lf.prim |= RT_LEAF_PRIM_NOISE;
+        }
         lf.visits = p.reserved;
         if (p.kind == RT_PRIM_GROUP) memcpy(&lf.visits, &p.f[5], 4); // a box: p1.z in the last word (visits do not matter to a surface)
         // self-contained forms (rt_bvh.h): a medium inside a sphere or a box, a moving sphere

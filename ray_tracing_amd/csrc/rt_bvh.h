@@ -58,10 +58,15 @@ typedef struct rt_bvh_node {
 #define RT_LEAF_MEDIUM_BOX 17
 #define RT_LEAF_MOVING_SPHERE 18
 
+/* rt_leaf.prim of a sphere, moving sphere or rect whose material has a noise texture carries this flag: a walk's best hit then
+ * says by itself that shading will ask for perlin noise, and the render kernel serves the few such lanes of a shade phase
+ * with the whole wave (rtf::wave_noise_value) before any of them has fetched anything. */
+#define RT_LEAF_PRIM_NOISE 0x40000000
+#define RT_LEAF_PRIM_MASK  0x3fffffff
 typedef struct rt_leaf {
     float    f[5];
     uint32_t kind_chain; /* rt_prim_kind | instance chain << 8 (of the shape; 0 = world space) */
-    int32_t  prim;       /* index into the primitive table returned by rt_bvh_build */
+    int32_t  prim;       /* index into the primitive table returned by rt_bvh_build (| RT_LEAF_PRIM_NOISE) */
     int32_t  visits;     /* times the reference's tree visits this primitive (rt_bvh.cpp); box: the bits of p1.z */
 } rt_leaf;
 
@@ -74,7 +79,8 @@ typedef struct rt_shade_rec {
     int32_t  texture;
     float    p0;       /* fuzz / ref_idx */
     float    color[3];
-    uint32_t pad[2];
+    uint32_t tex_kind; /* rt_texture_kind of `texture` (0 when texture = -1) and, for a noise texture, its scale: what the */
+    float    tex_scale;/* wave-level noise evaluation reads without fetching the texture record */
 } rt_shade_rec;
 
 /* Builds the tree over the primitives the entry array names (each once; a list that is a box is one item, the members of

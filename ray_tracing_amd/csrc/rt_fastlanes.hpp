@@ -330,7 +330,8 @@ RTF_DEV bool hit_bvh(const DevScene &S, const Ray &wr, float t_min, float t_max,
 // point, normal, (u,v), material of the winner; every lane for itself
 RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int prim, Surface &s)
 {
-    const rt_prim *prp = &S.fprims[prim < 0 ? 0 : prim];
+    prim = prim < 0 ? 0 : prim & RT_LEAF_PRIM_MASK;
+    const rt_prim *prp = &S.fprims[prim];
     s.p = fma3(t, wr.d, wr.o);
     s.u = s.v = 0.0f;
     s.face = prim;

@@ -46,8 +46,9 @@ static void walk(const rt_scene_desc *d, const std::vector<rt_bvh_node> &nodes, 
     if (ref == RT_BVH_NONE) return;
     st.depth = std::max(st.depth, depth);
     if (ref < 0) {
-        const rt_leaf &lf = leaves[~ref];
         ++st.leaves;
+        rt_leaf lf = leaves[~ref]; // (the flag for noise-textured primitives is not part of the index)
+        lf.prim &= RT_LEAF_PRIM_MASK;
         if (seen[lf.prim]++) ++st.dup;
         Box b;
         if (!world_box(d, d->prims[lf.prim], b)) ++st.bad_box;
@@ -60,7 +61,7 @@ static void walk(const rt_scene_desc *d, const std::vector<rt_bvh_node> &nodes, 
                              (lk == RT_LEAF_MOVING_SPHERE && pk == RT_PRIM_MOVING_SPHERE);
         if (!form_ok) ++st.bad_box;
         if (lk == RT_LEAF_MEDIUM_BOX || lk == RT_LEAF_MOVING_SPHERE) {
-            if ((size_t)(~ref) + 1 >= leaves.size() || leaves[~ref + 1].prim != lf.prim) ++st.bad_box;
+            if ((size_t)(~ref) + 1 >= leaves.size() || (leaves[~ref + 1].prim & RT_LEAF_PRIM_MASK) != lf.prim) ++st.bad_box;
             ++st.leaves; // the second slot
         }
         return;

@@ -154,6 +154,8 @@ def test_textures_on_the_device(kat, cornell):
         out = api.debug_eval(Raw, _capi.RT_EVAL_TEXTURE, it)
         assert np.allclose(out[:, 0], p[:, 6], rtol=0, atol=4e-6)  # noise: 0.5 (1 + sinf(...)), the device's sinf
         assert np.allclose(out[:, 3], p[:, 6], rtol=0, atol=2e-4)  # hardware sine of an argument of up to a few hundred radians
+        # the wave-level form the per-lane render kernel uses for a few lanes (56 lanes, one term each): the same terms in another order
+        assert np.allclose(out[:, 6], out[:, 3], rtol=0, atol=2e-5) and np.allclose(out[:, 6], p[:, 6], rtol=0, atol=2e-4)
     finally:
         lib.rt_scene_destroy(h)
 
