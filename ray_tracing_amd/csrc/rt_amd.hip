@@ -780,7 +780,8 @@ __device__ unsigned long long g_walk_counts[8];
 #define RT_COUNT_WAVE(k, any)
 #endif
 #ifdef RT_TIME_PHASES
-__device__ unsigned long long g_phase_cycles[8]; // wave cycles in [0] looks + refill + task hand-over, [1] node steps, [2] leaf tests, [3] surface, [4] shade
+__device__ unsigned long long g_phase_cycles[16]; // wave cycles in [0] looks + refill + task hand-over, [1] node steps, [2] leaf tests (entry, pop),
+// [3] surface, [4] shade; the leaf phase by branch: [5] fetch + decode + chain, [6] sphere, [7] rect, [8] moving sphere, [9] box, [10] medium, [11] join
 #endif
 template <int TEX, int BOX, int STEPS> // TEX: 0 constant colours only, 1 textures, 2 textures, a noise texture among them (with BOX = 2);
                                         // BOX: 0 / 1 / 2 = the leaf kinds walk_leaf is compiled for
@@ -832,8 +833,10 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
 #endif
 
 #ifdef RT_TIME_PHASES // development (tools/phase_times.py): cycles a wave spends in each phase of the loop
-    unsigned long long tp[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, tp_mark = clock64();
-#define RT_PHASE(k) do { const unsigned long long now_ = clock64(); tp[k] += now_ - tp_mark; tp_mark = now_; } while (0)
+    __shared__ unsigned long long tp_all[WAVES_PER_BLOCK][16];
+    unsigned long long *tp = tp_all[wave];
+    if (lane < 16) tp[lane] = lane == 15 ? clock64() : 0ull; // [15]: the time of the last stamp (rtf::phase_stamp)
+#define RT_PHASE(k) rtf::phase_stamp(tp, k)
 #else
 #define RT_PHASE(k)
 #endif
@@ -955,7 +958,11 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
             RT_COUNT(1, at_leaf);
             RT_COUNT_WAVE(5, __any(at_leaf));
             if (at_leaf) { // (a constant_medium draws, src/volume.h:43)
+#ifdef RT_TIME_PHASES
+                rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack, tp);
+#else
                 rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack);
+#endif
             }
         }
         RT_PHASE(2); // leaf tests
@@ -964,7 +971,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     flush_tile(acc, lane, tile_x, tile_y, A, s1 - s0, accum);
 #ifdef RT_TIME_PHASES
     if (lane == 0)
-        for (int k = 0; k < 5; ++k) atomicAdd(&g_phase_cycles[k], tp[k]);
+        for (int k = 0; k < 12; ++k) atomicAdd(&g_phase_cycles[k], tp[k]);
 #endif
 #undef RT_PHASE
 #ifdef RT_COUNT_WALK
@@ -2188,13 +2195,13 @@ extern "C" int rt_debug_walk_counts(unsigned long long *out8, int reset)
 
 #ifdef RT_TIME_PHASES
 // development builds only (tools/phase_times.py): wave cycles per phase of render_fastlanes_kernel since the last reset
-extern "C" int rt_debug_phase_cycles(unsigned long long *out4, int reset) // out4: eight counters
+extern "C" int rt_debug_phase_cycles(unsigned long long *out4, int reset) // out4: sixteen counters
 {
     void *p = nullptr;
     RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_cycles)));
     RT_HIP(hipDeviceSynchronize());
-    if (out4) RT_HIP(hipMemcpy(out4, p, 64, hipMemcpyDeviceToHost));
-    if (reset) RT_HIP(hipMemset(p, 0, 64));
+    if (out4) RT_HIP(hipMemcpy(out4, p, 128, hipMemcpyDeviceToHost));
+    if (reset) RT_HIP(hipMemset(p, 0, 128));
     return RT_OK;
 }
 #endif

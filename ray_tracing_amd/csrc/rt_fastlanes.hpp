@@ -200,9 +200,23 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
 // the lane's ray.  best_prim receives the leaf's rt_prim index.
 // BOX: which leaves the tree may hold besides static spheres and rects -- 0 none, 1 moving spheres, 2 anything (boxes, media).
 // Trees without them run kernels compiled without that code: fewer registers, no spills in the node loop.
-template <int BOX, class ST>
-RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, ST stack)
+#ifdef RT_TIME_PHASES // development (tools/phase_times.py): the leaf phase by branch, in the caller's counters 5..11
+// (tp: sixteen counters of the WAVE in LDS, [15] the time of the last stamp; the first lane that is on writes them, so a stamp
+// inside a branch counts whichever lanes took it.  The stamps themselves cost: with them the leaf phase weighs twice what it
+// weighs without, so only the split between the branches is to be read from them.)
+RTF_DEV void phase_stamp(unsigned long long *tp, int k)
 {
+    const unsigned long long now = clock64(), on = __ballot(true);
+    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(on >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)on, 0u)) == 0) tp[k] += now - tp[15], tp[15] = now;
+}
+#define RT_LEAF_CLOCK(k) do { if (tp) phase_stamp(tp, k); } while (0)
+#else
+#define RT_LEAF_CLOCK(k)
+#endif
+template <int BOX, class ST>
+RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, Rng &rng, ST stack, unsigned long long *tp = nullptr)
+{
+    RT_LEAF_CLOCK(2);
     const uint4 *q = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(S.leaves) + ((uint32_t)~w.cur << 5));
     const uint4 la = q[0], lb = q[1]; // f0 f1 f2 f3 | f4 kind_chain prim visits
     const int kind = (int)(lb.y & 255u), chain = (int)(lb.y >> 8);
@@ -217,6 +231,7 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
     }
     float t = 0.0f;
     bool h;
+    RT_LEAF_CLOCK(5); // fetch, decode, chain
     if (kind == RT_PRIM_SPHERE) { // src/sphere.h:21-59
         const V3 oc = v3(lr.o.x - __uint_as_float(la.x), lr.o.y - __uint_as_float(la.y), lr.o.z - __uint_as_float(la.z));
         const float radius = __uint_as_float(la.w);
@@ -227,6 +242,7 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         const bool in1 = (t1 < w.best_t) & (t1 > t_min), in2 = (t2 < w.best_t) & (t2 > t_min);
         t = in1 ? t1 : t2;
         h = (disc > 0.0f) & (in1 | in2);
+        RT_LEAF_CLOCK(6);
     } else if (kind >= RT_PRIM_XY_RECT && kind <= RT_PRIM_YZ_RECT) { // src/plane.h:9-29, 47-67, 109-129
         const bool xy = kind == RT_PRIM_XY_RECT, xz = kind == RT_PRIM_XZ_RECT;
         const float ok = xy ? lr.o.z : xz ? lr.o.y : lr.o.x, ik = xy ? inv.z : xz ? inv.y : inv.x;
@@ -236,6 +252,7 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
         h = (t >= t_min) & (t <= w.best_t) & (a >= __uint_as_float(la.x)) & (a <= __uint_as_float(la.y)) & (b >= __uint_as_float(la.z)) &
             (b <= __uint_as_float(la.w));
+        RT_LEAF_CLOCK(7);
     } else if (BOX == 0) { // (a tree of static spheres and rects only: the kernel is compiled without the rest)
         h = false;
     } else if (kind == RT_LEAF_MOVING_SPHERE) { // src/sphere.h:142-183, from the leaf's two slots (rt_bvh.h)
@@ -251,6 +268,7 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
         const bool in1 = (t1 < w.best_t) & (t1 > t_min), in2 = (t2 < w.best_t) & (t2 > t_min);
         t = in1 ? t1 : t2;
         h = (disc > 0.0f) & (in1 | in2);
+        RT_LEAF_CLOCK(8);
     } else if (BOX < 2) { // (no boxes or media in the tree: the kernel is compiled without them)
         h = false;
     } else if (kind == RT_PRIM_GROUP) { // a box: one slab test for its six faces
@@ -259,6 +277,7 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
                                    v3(__uint_as_float(la.w), __uint_as_float(lb.x), __uint_as_float(lb.w)), lr, inv, tn, tf);
         t = tn >= t_min ? tn : tf;
         h = cut & (t >= t_min) & (t <= w.best_t);
+        RT_LEAF_CLOCK(9);
     } else { // constant_medium::hit, src/volume.h:23-53 (with its line-41 assignment); or a primitive the leaf only names
         // the boundary's first hit on the whole line, then the first one after it
         float t1 = 0.0f, t2 = 0.0f, density = 1.0f;
@@ -306,7 +325,9 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
                 }
             }
         }
+        RT_LEAF_CLOCK(10);
     }
+    RT_LEAF_CLOCK(11); // the join
     const bool take = h & (t <= w.best_t);
     w.best_t = take ? t : w.best_t;
     w.best_prim = take ? (int)lb.z : w.best_prim;

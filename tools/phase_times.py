@@ -25,10 +25,15 @@ for job in jobs:
     lib.rt_debug_phase_cycles(None, 1)
     api.render(sc, acc, nx, ny, 0, spp)
     torch.cuda.synchronize()
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     lib.rt_debug_phase_cycles(out, 1)
-    t = [int(x) for x in out][:5]
+    t = [int(x) for x in out][:12]
     tot = sum(t) or 1
+    t[2] += sum(t[5:12])
+    leaf = t[2] or 1
     print(f"{name} {nx}x{ny}x{spp}: looks+refill+hand-over {100 * t[0] / tot:.1f} %, surface {100 * t[3] / tot:.1f} %, shade {100 * t[4] / tot:.1f} %, "
           f"node steps {100 * t[1] / tot:.1f} %, leaf tests {100 * t[2] / tot:.1f} % of the waves' time ({sc.last_render_ms():.2f} ms)", flush=True)
+    print("    leaf phase by branch (the stamps weigh: read the split, not the share): " + ", ".join(f"{n} {100 * t[k] / leaf:.1f} %" for k, n in
+          ((5, "fetch + decode + chain"), (6, "sphere"), (7, "rect"), (8, "moving sphere"), (9, "box"), (10, "medium"), (11, "join"))) +
+          " (the rest: entry and pop)", flush=True)
     sc.close()
