@@ -872,7 +872,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
                 rtf::Surface sf;
                 sf.p = r.o; // a miss ends the path; shade still writes the (dead) ray from it
                 RT_PHASE(0);
-                if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
+                if (hit_any) rtf::build_surface_lanes<BOX>(S, r, w.best_t, w.best_prim, sf);
                 if (TEX == 2 && noise_c >= 0.0f) sf.color = v3(noise_c, noise_c, noise_c), sf.texture = -1;
                 RT_PHASE(3);
                 V3 L;
@@ -1188,7 +1188,7 @@ void render_fastlanes_block_kernel(DevScene S, const uint32_t *__restrict__ recs
             const bool hit_any = w.best_prim >= 0;
             rtf::Surface sf;
             sf.p = r.o; // a miss ends the path; shade still writes the (dead) ray from it
-            if (hit_any) rtf::build_surface_lanes(S, r, w.best_t, w.best_prim, sf);
+            if (hit_any) rtf::build_surface_lanes<(BOX ? 2 : 0)>(S, r, w.best_t, w.best_prim, sf);
             V3 L;
             if (!rtf::shade<TEX>(S, recs, Y, hit_any, sf, r, T, depth, A.max_depth, rng, L)) {
                 alive = false;
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(256) void trace_fastlanes_kernel(DevScene S, int n,
     sf.p = sf.n = v3(0, 0, 0), sf.u = sf.v = 0.0f;
     rt_hit o;
     sf.face = prim;
-    if (any) rtf::build_surface_lanes(S, r, t, prim, sf);
+    if (any) rtf::build_surface_lanes<2>(S, r, t, prim, sf);
     o.prim_id = any ? S.fprims[sf.face].user_id : -1; // a box names the face rect that was hit
     o.material = any ? S.fprims[sf.face].material : -1;
     o.t = any ? t : 0.0f, o.u = sf.u, o.v = sf.v;
@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(256) void debug_bounce_lanes_kernel(DevScene S, con
     if (!alive) return;
     rtf::Surface sf;
     sf.p = r.o, sf.n = v3(0, 0, 0), sf.u = sf.v = 0.0f, sf.face = prim, sf.mat_kind = 0u, sf.texture = -1, sf.p0 = 0.0f, sf.color = v3(0, 0, 0);
-    if (any) rtf::build_surface_lanes(S, r, t, prim, sf);
+    if (any) rtf::build_surface_lanes<2>(S, r, t, prim, sf);
     V3 T = v3(1, 1, 1), L = v3(0, 0, 0);
     int depth = 0;
     const bool go = rtf::shade<true>(S, recs, Y, any, sf, r, T, depth, 50, rng, L);

@@ -348,19 +348,31 @@ RTF_DEV bool hit_bvh(const DevScene &S, const Ray &wr, float t_min, float t_max,
     return best_prim >= 0;
 }
 
-// point, normal, (u,v), material of the winner; every lane for itself
+// point, normal, (u,v), material of the winner; every lane for itself.  BOX as walk_leaf's: the leaf kinds the tree may hold.
+// The primitive's record and its shade record (rt_bvh.h) are fetched in ONE round: read field by field, each behind a branch on
+// the one before (kind, then chain, then f, then flags, then the shade record), a shaded ray waited for memory four or five times
+// in a row.
+template <int BOX>
 RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int prim, Surface &s)
 {
     prim = prim < 0 ? 0 : prim & RT_LEAF_PRIM_MASK;
-    const rt_prim *prp = &S.fprims[prim];
+    const uint4 *pq = reinterpret_cast<const uint4 *>(S.fprims + prim);
+    const uint4 h0 = pq[0], g0 = pq[2], g1 = pq[3]; // kind flags material chain | f[0..3] | f[4..7]
+    const uint4 *sq = reinterpret_cast<const uint4 *>(S.fshade + prim);
+    uint4 sa = sq[0], sb = sq[1];
+    const int kind = (int)h0.x, chain = (int)h0.w;
+    const uint32_t flags = h0.y;
+    const float f0 = __uint_as_float(g0.x), f1 = __uint_as_float(g0.y), f2 = __uint_as_float(g0.z), f3 = __uint_as_float(g0.w);
+    const float f4 = __uint_as_float(g1.x), f5 = __uint_as_float(g1.y), f6 = __uint_as_float(g1.z), f7 = __uint_as_float(g1.w);
     s.p = fma3(t, wr.d, wr.o);
     s.u = s.v = 0.0f;
     s.face = prim;
     V3 n = v3(1, 0, 0); // constant_medium: src/volume.h:47
-    if (prp->kind == RT_PRIM_GROUP) { // a box: the face whose plane holds the point, its outward normal, its rect's material
-        const Ray lr = prp->chain == 0 ? wr : rt::chain_down(S, prp->chain, wr);
+    if (BOX == 2 && kind == RT_PRIM_GROUP) { // a box: the face whose plane holds the point, its outward normal, its rect's material
+        const int first = (int)pq[1].x;
+        const Ray lr = chain == 0 ? wr : rt::chain_down(S, chain, wr);
         const V3 pl = fma3(t, lr.d, lr.o);
-        const V3 lo = v3(prp->f[0], prp->f[1], prp->f[2]), hi = v3(prp->f[3], prp->f[4], prp->f[5]);
+        const V3 lo = v3(f0, f1, f2), hi = v3(f3, f4, f5);
         const V3 q = v3(pl.x - 0.5f * (lo.x + hi.x), pl.y - 0.5f * (lo.y + hi.y), pl.z - 0.5f * (lo.z + hi.z));
         const float ex = fabsf(q.x) - 0.5f * (hi.x - lo.x), ey = fabsf(q.y) - 0.5f * (hi.y - lo.y), ez = fabsf(q.z) - 0.5f * (hi.z - lo.z);
         const bool is_x = (ex >= ey) & (ex >= ez), is_y = !is_x & (ey >= ez);
@@ -368,52 +380,45 @@ RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int 
         const float qa = is_x ? q.x : is_y ? q.y : q.z;
         const float sg = qa < 0.0f ? -1.0f : 1.0f;
         n = v3(is_x ? sg : 0.0f, is_y ? sg : 0.0f, (is_x | is_y) ? 0.0f : sg);
-        if (prp->chain != 0) {
+        if (chain != 0) {
             V3 dummy = pl;
-            rt::chain_up(S, prp->chain, dummy, n);
+            rt::chain_up(S, chain, dummy, n);
         }
-        s.face = prp->first + 2 * axis + (qa < 0.0f ? 0 : 1);
-        prp = &S.fprims[s.face];
-    }
-    const rt_prim &pr = *prp;
-    const int kind = pr.kind;
-    if ((kind != RT_PRIM_MEDIUM) & (s.face == prim)) {
-        const Ray lr = pr.chain == 0 ? wr : rt::chain_down(S, pr.chain, wr);
+        s.face = first + 2 * axis + (qa < 0.0f ? 0 : 1);
+        const uint4 *fq = reinterpret_cast<const uint4 *>(S.fshade + s.face); // the face rect's material: the one fetch that waits for another
+        sa = fq[0], sb = fq[1];
+    } else if (kind != RT_PRIM_MEDIUM) {
+        const Ray lr = chain == 0 ? wr : rt::chain_down(S, chain, wr);
         const V3 pl = fma3(t, lr.d, lr.o);
         if (kind <= RT_PRIM_MOVING_SPHERE) {
-            V3 c;
-            float radius;
-            if (kind == RT_PRIM_SPHERE) {
-                c = v3(pr.f[0], pr.f[1], pr.f[2]);
-                radius = pr.f[3];
-            } else {
-                const float k = (lr.time - pr.f[7]) * rcp(pr.f[8] - pr.f[7]);
-                c = v3(fmaf(k, pr.f[3] - pr.f[0], pr.f[0]), fmaf(k, pr.f[4] - pr.f[1], pr.f[1]), fmaf(k, pr.f[5] - pr.f[2], pr.f[2]));
-                radius = pr.f[6];
+            V3 c = v3(f0, f1, f2);
+            float radius = f3;
+            if (BOX >= 1 && kind == RT_PRIM_MOVING_SPHERE) { // f = c0 c1 r t0 t1 (include/rt_amd.h)
+                const float f8 = __uint_as_float(pq[4].x);
+                const float k = (lr.time - f7) * rcp(f8 - f7);
+                c = v3(fmaf(k, f3 - f0, f0), fmaf(k, f4 - f1, f1), fmaf(k, f5 - f2, f2));
+                radius = f6;
             }
             const float ir = rcp(radius);
             n = v3((pl.x - c.x) * ir, (pl.y - c.y) * ir, (pl.z - c.z) * ir);
-            if (pr.flags & RT_PRIM_NEEDS_UV) rt::sphere_uv(n, s.u, s.v); // before the flip, as sphere::hit does
+            if (flags & RT_PRIM_NEEDS_UV) rt::sphere_uv(n, s.u, s.v); // before the flip, as sphere::hit does
         } else {
             const bool xy = kind == RT_PRIM_XY_RECT, xz = kind == RT_PRIM_XZ_RECT;
             n = v3((xy | xz) ? 0.0f : 1.0f, xz ? 1.0f : 0.0f, xy ? 1.0f : 0.0f);
-            if (pr.flags & RT_PRIM_NEEDS_UV) {
+            if (flags & RT_PRIM_NEEDS_UV) {
                 const float a = (xy | xz) ? pl.x : pl.y, b = xy ? pl.y : pl.z;
-                s.u = (a - pr.f[0]) * rcp(pr.f[1] - pr.f[0]);
-                s.v = (b - pr.f[2]) * rcp(pr.f[3] - pr.f[2]);
+                s.u = (a - f0) * rcp(f1 - f0);
+                s.v = (b - f2) * rcp(f3 - f2);
             }
         }
-        if (pr.flags & RT_PRIM_FLIP) n = v3(-n.x, -n.y, -n.z);
-        if (pr.chain != 0) {
+        if (flags & RT_PRIM_FLIP) n = v3(-n.x, -n.y, -n.z);
+        if (chain != 0) {
             V3 dummy = pl;
-            rt::chain_up(S, pr.chain, dummy, n);
+            rt::chain_up(S, chain, dummy, n);
         }
     }
     s.n = n;
-    // material and texture, resolved on the host into one record per primitive (rt_bvh.h): for everything but a box it is
-    // fetched beside the primitive, not after it
-    const uint4 *sq = reinterpret_cast<const uint4 *>(S.fshade + s.face);
-    const uint4 sa = sq[0], sb = sq[1];
+    // material and texture, resolved on the host into one record per primitive (rt_bvh.h)
     s.mat_kind = sa.x;
     s.texture = (int32_t)sa.y;
     s.p0 = __uint_as_float(sa.z);
