@@ -179,17 +179,20 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
     const float tn1 = fmaxf(fmax3(plane_lo(bx, i.x, n.x), plane_lo(by, i.y, n.y), plane_lo(bz, i.z, n.z)), t_min);
     const float tf1 = fminf(fmin3(plane_hi(bx, i.x, n.x), plane_hi(by, i.y, n.y), plane_hi(bz, i.z, n.z)), w.best_t);
     const int ref0 = (int)a.w, ref1 = (int)b.w;
-    const bool h0 = tf0 >= tn0, h1 = (tf1 >= tn1) & (ref1 != RT_BVH_NONE);
     // "First" is the box to open now: the only one that was hit, or of two the nearer.  It is to be opened if either was hit
-    // and the other one pushed if both were -- said with lane masks and scalar logic only (selects between booleans, as in
-    // "was the nearer one hit", make the compiler turn them into 0 / 1 registers and back: a dozen vector instructions per
-    // step; and a select on the distances instead, "a missed box is infinitely far", costs the kernels with box leaves 30
-    // bytes of spills per lane).
+    // and the other one pushed if both were.  Said with LANE MASKS in scalar registers (ballots of the comparisons, scalar
+    // logic, and back to a condition with inverse_ballot): left to itself hipcc turns selects between booleans, and booleans
+    // that live across the push, into 0 / 1 vector registers and and-s, or-s and compares them there -- a dozen vector
+    // instructions per step at first, seven after the first rewrite, none now.  (A select on the distances instead, "a missed
+    // box is infinitely far", costs the kernels with box leaves 30 bytes of spills per lane.)
     // A ray that starts inside both boxes enters both at t_min: the box it leaves first -- the tighter one -- goes first
     // (random spheres +2 %, 1M spheres +1 %).
-    const bool first0 = h0 & (!h1 | (tn0 < tn1) | ((tn0 == tn1) & (tf0 <= tf1)));
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(tf0 >= tn0);
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(tf1 >= tn1) & __builtin_amdgcn_ballot_w64(ref1 != RT_BVH_NONE);
+    const unsigned long long nearer0 = __builtin_amdgcn_ballot_w64(tn0 < tn1) | (__builtin_amdgcn_ballot_w64(tn0 == tn1) & __builtin_amdgcn_ballot_w64(tf0 <= tf1));
+    const bool first0 = __builtin_amdgcn_inverse_ballot_w64(m0 & (~m1 | nearer0));
     const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
-    const bool hit_near = h0 | h1, hit_far = h0 & h1;
+    const bool hit_near = __builtin_amdgcn_inverse_ballot_w64(m0 | m1), hit_far = __builtin_amdgcn_inverse_ballot_w64(m0 & m1);
     if (hit_far) stack_push(stack, w.sp, far);
     int next = near;
     if (!hit_near) next = walk_pop(w, stack);
