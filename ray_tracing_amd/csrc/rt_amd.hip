@@ -1453,7 +1453,7 @@ struct rt_scene {
     bool fast_flat = false;     // the record stream holds no box records and is stored in runs
     bool lanes_ok = false;      // the scene does not fit the table but the per-lane fast path (rt_fastlanes.hpp) can run it
     bool lanes_boxes = false;   // its tree holds leaves other than static spheres and rects: boxes (rt_box.h), media, moving spheres
-    int lanes_leaf_kinds = 0;   // 0: static spheres and rects only; 1: + moving spheres; 2: anything (render_fastlanes_kernel's BOX)
+    int lanes_leaf_kinds = 0;   // 0: static spheres and rects in world space only; 1: + moving spheres; 2: anything (render_fastlanes_kernel's BOX)
     int bvh_levels = 1;         // inner levels of that tree (rt_bvh_build)
     bool lanes_small = false;   // that tree has fewer than 32767 nodes and leaves: its references fit the 16-bit home stacks of render_fastlanes_block_kernel
     const char *fast_why = "";
@@ -1737,6 +1737,7 @@ extern "C" int rt_scene_create_flags(const rt_scene_desc *d, int device, uint32_
     for (const rt_leaf &lf : leaves) { // anything but static spheres and rects: the kernels with (more of) the rest of walk_leaf
         s->lanes_noise |= (lf.prim & RT_LEAF_PRIM_NOISE) != 0;
         const uint32_t k = lf.kind_chain & 255u;
+        if ((lf.kind_chain >> 8) != 0u) s->lanes_leaf_kinds = 2, s->lanes_boxes = true; // under an instance chain: only the kernels for "anything" take rays down chains
         if (k == RT_PRIM_SPHERE || k == RT_PRIM_XY_RECT || k == RT_PRIM_XZ_RECT || k == RT_PRIM_YZ_RECT) continue;
         s->lanes_boxes = true;
         s->lanes_leaf_kinds = std::max(s->lanes_leaf_kinds, k == RT_LEAF_MOVING_SPHERE ? 1 : 2);

@@ -201,7 +201,8 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
 
 // lanes with cur < 0 (and not NONE): leaf ~cur (rt_bvh.h: 32 bytes, what the test of a sphere or rect reads) against
 // the lane's ray.  best_prim receives the leaf's rt_prim index.
-// BOX: which leaves the tree may hold besides static spheres and rects -- 0 none, 1 moving spheres, 2 anything (boxes, media).
+// BOX: which leaves the tree may hold besides static spheres and rects IN WORLD SPACE -- 0 none, 1 moving spheres (in world
+// space), 2 anything (boxes, media, leaves under an instance chain).
 // Trees without them run kernels compiled without that code: fewer registers, no spills in the node loop.
 #ifdef RT_TIME_PHASES // development (tools/phase_times.py): the leaf phase by branch, in the caller's counters 5..11
 // (tp: sixteen counters of the WAVE in LDS, [15] the time of the last stamp; the first lane that is on writes them, so a stamp
@@ -228,7 +229,7 @@ RTF_DEV void walk_leaf(const DevScene &S, Walk &w, const Ray &wr, float t_min, R
     const float w_dd = ref_dot(wr.d, wr.d), w_inv_dd = rcp(w_dd);
     Ray lr = wr;
     V3 inv = w.winv;
-    if (chain != 0) {
+    if (BOX == 2 && chain != 0) { // (BOX < 2: every leaf is in world space, and the ray is not copied: eight moves per leaf test)
         lr = rt::chain_down(S, chain, wr);
         inv = rcp3(lr.d);
     }
@@ -391,7 +392,8 @@ RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int 
         const uint4 *fq = reinterpret_cast<const uint4 *>(S.fshade + s.face); // the face rect's material: the one fetch that waits for another
         sa = fq[0], sb = fq[1];
     } else if (kind != RT_PRIM_MEDIUM) {
-        const Ray lr = chain == 0 ? wr : rt::chain_down(S, chain, wr);
+        const bool chained = BOX == 2 && chain != 0; // (BOX < 2: every leaf is in world space)
+        const Ray lr = !chained ? wr : rt::chain_down(S, chain, wr);
         const V3 pl = fma3(t, lr.d, lr.o);
         if (kind <= RT_PRIM_MOVING_SPHERE) {
             V3 c = v3(f0, f1, f2);
@@ -415,7 +417,7 @@ RTF_DEV void build_surface_lanes(const DevScene &S, const Ray &wr, float t, int 
             }
         }
         if (flags & RT_PRIM_FLIP) n = v3(-n.x, -n.y, -n.z);
-        if (chain != 0) {
+        if (chained) {
             V3 dummy = pl;
             rt::chain_up(S, chain, dummy, n);
         }
