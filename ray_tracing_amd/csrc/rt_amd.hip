@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const uint32_t *__restr
 #ifdef RT_COUNT_WALK // development (tools/work_counts.py): what the walks of a launch touch -- the algorithmic bytes of the roofline
 // [0] node steps (one 32-byte node each), [1] leaf tests (one 32-byte leaf each), [2] rays, [3] paths: per lane;
 // [4] node steps, [5] leaf phases, [6] shade phases a WAVE ran (whatever the number of lanes on), [7] lanes shaded
-__device__ unsigned long long g_walk_counts[8];
+__device__ unsigned long long g_walk_counts[16]; // [8..10]: leaf phases that held one / two / three classes of leaves (spheres and rects | boxes | the rest)
 #define RT_COUNT(k, cond) n_count[k] += (cond) ? 1u : 0u
 #define RT_COUNT_WAVE(k, any) do { const bool any_ = (any); n_count[k] += (lane == 0 && any_) ? 1u : 0u; } while (0)
 #else
@@ -829,7 +829,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
     rtf::Walk w;
     rtf::walk_start(w, r, RT_FLT_MAX, false);
 #ifdef RT_COUNT_WALK
-    unsigned n_count[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    unsigned n_count[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #endif
 
 #ifdef RT_TIME_PHASES // development (tools/phase_times.py): cycles a wave spends in each phase of the loop
@@ -957,6 +957,19 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
         if (__popcll(__ballot(at_leaf)) >= A.leaf_batch || !__any(w.cur >= 0)) {
             RT_COUNT(1, at_leaf);
             RT_COUNT_WAVE(5, __any(at_leaf));
+#ifdef RT_COUNT_WALK
+            {
+                int cls = -1;
+                if (at_leaf) {
+                    const uint32_t lk = S.leaves[~w.cur].kind_chain & 255u;
+                    cls = (lk <= RT_PRIM_YZ_RECT || lk == RT_LEAF_MOVING_SPHERE) ? 0 : lk == RT_PRIM_GROUP ? 1 : 2;
+                }
+                const int n_cls = (__any(cls == 0) ? 1 : 0) + (__any(cls == 1) ? 1 : 0) + (__any(cls == 2) ? 1 : 0);
+                RT_COUNT_WAVE(8, n_cls == 1);
+                RT_COUNT_WAVE(9, n_cls == 2);
+                RT_COUNT_WAVE(10, n_cls == 3);
+            }
+#endif
             if (at_leaf) { // (a constant_medium draws, src/volume.h:43)
 #ifdef RT_TIME_PHASES
                 rtf::walk_leaf<BOX>(S, w, r, 0.001f, rng, stack, tp);
@@ -975,7 +988,7 @@ void render_fastlanes_kernel(DevScene S, const uint32_t *__restrict__ recs,
 #endif
 #undef RT_PHASE
 #ifdef RT_COUNT_WALK
-    for (int k = 0; k < 8; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
+    for (int k = 0; k < 16; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
 #endif
 }
 
@@ -1061,7 +1074,7 @@ void render_fastlanes_block_kernel(DevScene S, const uint32_t *__restrict__ recs
     rtf::Walk w;
     rtf::walk_start(w, r, RT_FLT_MAX, false);
 #ifdef RT_COUNT_WALK
-    unsigned n_count[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    unsigned n_count[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #endif
 
     for (;;) {
@@ -1114,6 +1127,19 @@ void render_fastlanes_block_kernel(DevScene S, const uint32_t *__restrict__ recs
             const bool at_leaf = (w.cur < 0) & (w.cur != RT_BVH_NONE);
             RT_COUNT(1, at_leaf);
             RT_COUNT_WAVE(5, __any(at_leaf));
+#ifdef RT_COUNT_WALK
+            {
+                int cls = -1;
+                if (at_leaf) {
+                    const uint32_t lk = S.leaves[~w.cur].kind_chain & 255u;
+                    cls = (lk <= RT_PRIM_YZ_RECT || lk == RT_LEAF_MOVING_SPHERE) ? 0 : lk == RT_PRIM_GROUP ? 1 : 2;
+                }
+                const int n_cls = (__any(cls == 0) ? 1 : 0) + (__any(cls == 1) ? 1 : 0) + (__any(cls == 2) ? 1 : 0);
+                RT_COUNT_WAVE(8, n_cls == 1);
+                RT_COUNT_WAVE(9, n_cls == 2);
+                RT_COUNT_WAVE(10, n_cls == 3);
+            }
+#endif
             if (at_leaf) rtf::walk_leaf<(BOX ? 2 : 0)>(S, w, r, 0.001f, rng, stack); // (a constant_medium draws, src/volume.h:43)
         }
 
@@ -1214,7 +1240,7 @@ void render_fastlanes_block_kernel(DevScene S, const uint32_t *__restrict__ recs
     if (!A.chain) flush(A.atomic_out != 0);
     else flush(true); // the last tile (every other one went out when the block moved on)
 #ifdef RT_COUNT_WALK
-    for (int k = 0; k < 8; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
+    for (int k = 0; k < 16; ++k) atomicAdd(&g_walk_counts[k], (unsigned long long)n_count[k]);
 #endif
 }
 
@@ -2188,8 +2214,8 @@ extern "C" int rt_debug_walk_counts(unsigned long long *out8, int reset)
     void *p = nullptr;
     RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_walk_counts)));
     RT_HIP(hipDeviceSynchronize());
-    if (out8) RT_HIP(hipMemcpy(out8, p, 64, hipMemcpyDeviceToHost));
-    if (reset) RT_HIP(hipMemset(p, 0, 64));
+    if (out8) RT_HIP(hipMemcpy(out8, p, 128, hipMemcpyDeviceToHost)); // (sixteen counters)
+    if (reset) RT_HIP(hipMemset(p, 0, 128));
     return RT_OK;
 }
 #endif

@@ -51,9 +51,9 @@ def gpu_counts(name, nx, ny, spp):
     lib.rt_debug_walk_counts(None, 1)
     api.render(sc, acc, nx, ny, 0, spp)
     torch.cuda.synchronize()
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     lib.rt_debug_walk_counts(out, 1)
-    nodes, leaves, rays, paths, w_nodes, w_leaves, w_shades, shaded = [int(x) for x in out]
+    nodes, leaves, rays, paths, w_nodes, w_leaves, w_shades, shaded = [int(x) for x in out][:8]
     print(f"{name}: lanes on per wave-level node step {nodes / max(w_nodes, 1):.1f}, per leaf phase {leaves / max(w_leaves, 1):.1f}, "
           f"per shade phase {shaded / max(w_shades, 1):.1f}; per path: {w_nodes * 64 / paths:.1f} node-step lane slots for {nodes / paths:.1f} steps, "
           f"{w_leaves * 64 / paths:.1f} leaf slots for {leaves / paths:.1f} tests, {w_shades * 64 / paths:.1f} shade slots for {shaded / paths:.1f} shadings")
