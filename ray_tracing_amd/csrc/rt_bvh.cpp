@@ -185,6 +185,25 @@ struct Builder {
                     if (cost < best_cost) best_cost = cost, best_axis = k, best_bin = i;
                 }
             }
+            // One more candidate: the LARGEST item alone against all the others.  Bins of centroids cannot isolate an item whose
+            // centre lies among the others' -- a scene-wide fog, a ground plane of one piece -- so it sank to the bottom of the
+            // tree and every box above it was the whole scene (Next-Week final: every ray opened the eleven ancestors of the fog).
+            if (depth + 1 + log2_ceil(n - 1) < limit - 1) {
+                size_t big = a;
+                for (size_t i = a + 1; i < b; ++i)
+                    if (items[i].b.area() > items[big].b.area()) big = i;
+                Box rest;
+                rest.clear();
+                for (size_t i = a; i < b; ++i)
+                    if (i != big) rest.add(items[i].b);
+                const float cost = items[big].b.area() + rest.area() * (float)(n - 1);
+                if (cost < best_cost) {
+                    std::swap(items[a], items[big]);
+                    mid = a + 1;
+                    split_done = true;
+                    best_axis = -1;
+                }
+            }
             if (best_axis >= 0) {
                 const float ext = cb.hi[best_axis] - cb.lo[best_axis], scale = 16 / ext, lo = cb.lo[best_axis];
                 const int bax = best_axis, bbin = best_bin;

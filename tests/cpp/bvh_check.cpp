@@ -114,6 +114,13 @@ int main(int argc, char **argv)
                 st.missing += seen[d->entries[e].a] != 1;
             }
         }
+        if (ok && !nodes.empty()) // the top of the tree: which references are leaves (a scene-wide primitive ends up beside the root)
+            printf("%s: root children %s / %s", argv[a], nodes[0].ref0 < 0 ? "LEAF" : "node", nodes[0].ref1 < 0 ? (nodes[0].ref1 == RT_BVH_NONE ? "none" : "LEAF") : "node");
+        if (ok && !nodes.empty() && nodes[0].ref0 >= 0)
+            printf("; of child 0: %s / %s", nodes[nodes[0].ref0].ref0 < 0 ? "LEAF" : "node", nodes[nodes[0].ref0].ref1 < 0 ? "LEAF" : "node");
+        if (ok && !nodes.empty() && nodes[0].ref1 >= 0)
+            printf("; of child 1: %s / %s", nodes[nodes[0].ref1].ref0 < 0 ? "LEAF" : "node", nodes[nodes[0].ref1].ref1 < 0 ? "LEAF" : "node");
+        if (ok) printf("\n");
         std::vector<int32_t> order;
         int odepth = 0;
         const bool ordered = rt_order_build(d, order, &odepth);
