@@ -37,13 +37,23 @@ static int check_halves()
 
 struct Stats {
     int nodes = 0, leaves = 0, depth = 0, bad_box = 0, dup = 0, missing = 0;
+    // what the half-float rounding costs: the surface area (~ the chance that a ray enters) of the boxes as stored against the
+    // exact boxes of the same subtrees, over the boxes of leaves and over those of inner nodes
+    double leaf_area_half = 0, leaf_area_exact = 0, node_area_half = 0, node_area_exact = 0;
 };
+static double box_area(const float lo[3], const float hi[3])
+{
+    const double e[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
+    return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+}
 
 // every leaf's primitive box (world space, recomputed here) must lie inside the half-float box its parent holds for it
-static void walk(const rt_scene_desc *d, const std::vector<rt_bvh_node> &nodes, const std::vector<rt_leaf> &leaves, int32_t ref,
+static Box walk(const rt_scene_desc *d, const std::vector<rt_bvh_node> &nodes, const std::vector<rt_leaf> &leaves, int32_t ref,
                  const float lo[3], const float hi[3], int depth, std::vector<int> &seen, Stats &st)
 {
-    if (ref == RT_BVH_NONE) return;
+    Box exact;
+    exact.clear();
+    if (ref == RT_BVH_NONE) return exact;
     st.depth = std::max(st.depth, depth);
     if (ref < 0) {
         ++st.leaves;
@@ -64,7 +74,8 @@ static void walk(const rt_scene_desc *d, const std::vector<rt_bvh_node> &nodes, 
             if ((size_t)(~ref) + 1 >= leaves.size() || (leaves[~ref + 1].prim & RT_LEAF_PRIM_MASK) != lf.prim) ++st.bad_box;
             ++st.leaves; // the second slot
         }
-        return;
+        if (std::isfinite(lo[0]) && std::isfinite(box_area(lo, hi))) st.leaf_area_half += box_area(lo, hi), st.leaf_area_exact += box_area(b.lo, b.hi);
+        return b;
     }
     ++st.nodes;
     const rt_bvh_node &n = nodes[ref];
@@ -75,8 +86,12 @@ static void walk(const rt_scene_desc *d, const std::vector<rt_bvh_node> &nodes, 
         if (!(lo[k] <= l0[k] && h0[k] <= hi[k])) ++st.bad_box;
         if (n.ref1 != RT_BVH_NONE && !(lo[k] <= l1[k] && h1[k] <= hi[k])) ++st.bad_box;
     }
-    walk(d, nodes, leaves, n.ref0, l0, h0, depth + 1, seen, st);
-    walk(d, nodes, leaves, n.ref1, l1, h1, depth + 1, seen, st);
+    const Box e0 = walk(d, nodes, leaves, n.ref0, l0, h0, depth + 1, seen, st);
+    const Box e1 = walk(d, nodes, leaves, n.ref1, l1, h1, depth + 1, seen, st);
+    exact.add(e0);
+    if (n.ref1 != RT_BVH_NONE) exact.add(e1);
+    if (std::isfinite(lo[0]) && std::isfinite(box_area(lo, hi))) st.node_area_half += box_area(lo, hi), st.node_area_exact += box_area(exact.lo, exact.hi);
+    return exact;
 }
 
 int main(int argc, char **argv)
@@ -121,6 +136,9 @@ int main(int argc, char **argv)
         if (ok && !nodes.empty() && nodes[0].ref1 >= 0)
             printf("; of child 1: %s / %s", nodes[nodes[0].ref1].ref0 < 0 ? "LEAF" : "node", nodes[nodes[0].ref1].ref1 < 0 ? "LEAF" : "node");
         if (ok) printf("\n");
+        if (ok)
+            printf("%s: area of the stored (half-float) boxes / exact boxes: leaves %.3f, inner nodes %.3f\n", argv[a],
+                   st.leaf_area_half / std::max(st.leaf_area_exact, 1e-30), st.node_area_half / std::max(st.node_area_exact, 1e-30));
         std::vector<int32_t> order;
         int odepth = 0;
         const bool ordered = rt_order_build(d, order, &odepth);
