@@ -359,7 +359,9 @@ enum rt_option {
     RT_OPT_LEAF_BATCH = 10,         /* per-lane walk: lanes standing on a leaf wait until this many do */
     RT_OPT_LANES_REGROUP = 11,      /* per-lane walk, trees of fewer than 32767 nodes and leaves: 1 = the block kernel that regroups its
                                        paths every few node steps, 0 = the wave kernel (default: the library's choice) */
-    RT_OPT_REGROUP_ROUNDS = 12      /* that kernel: rounds of (two node steps + one leaf test) between two regroups */
+    RT_OPT_REGROUP_ROUNDS = 12,     /* that kernel: rounds of (two node steps + one leaf test) between two regroups */
+    RT_OPT_BLOCK_WAVES = 13         /* block kernel: waves of a block, 4 (a 16x16 tile) or 8 (32x16; chained launches only);
+                                       0 (default): 8 for launches of at least 2^27 paths */
 };
 enum rt_path { RT_PATH_AUTO = 0, RT_PATH_EXACT = 1, RT_PATH_FAST = 2 };
 int rt_scene_set_option(rt_scene* scene, int option, int value);

@@ -18,7 +18,7 @@ RT_RENDER_ACCUMULATE = 1
 RT_TRACE_NOALLOC_MAX_RAYS = 65536
 RT_OPT_RENDER_PATH, RT_OPT_TRACE_PATH = 1, 2
 (RT_OPT_BLOCK_KERNEL, RT_OPT_CHAIN_TASKS, RT_OPT_TARGET_TASKS, RT_OPT_PATHS_PER_LANE, RT_OPT_NODE_STEPS,
- RT_OPT_CHAIN_BLOCKS_PER_CU, RT_OPT_SHADE_BATCH, RT_OPT_LEAF_BATCH, RT_OPT_LANES_REGROUP, RT_OPT_REGROUP_ROUNDS) = range(3, 13)
+ RT_OPT_CHAIN_BLOCKS_PER_CU, RT_OPT_SHADE_BATCH, RT_OPT_LEAF_BATCH, RT_OPT_LANES_REGROUP, RT_OPT_REGROUP_ROUNDS, RT_OPT_BLOCK_WAVES) = range(3, 14)
 (RT_EVAL_LIGHT_PDF, RT_EVAL_ONB, RT_EVAL_ONB_FAST, RT_EVAL_OPTICS, RT_EVAL_PERLIN, RT_EVAL_TEXTURE, RT_EVAL_SAMPLERS, RT_EVAL_BOUNCE,
  RT_EVAL_BOUNCE_FAST) = range(1, 10)
 RT_CREATE_KEEP_BOX_RECORDS = 1

@@ -1496,6 +1496,7 @@ struct rt_scene {
     // rt_scene_set_option: tuning / test switches of rt_render (0 = the library's choice)
     int opt_block_kernel = 1, opt_chain = 1, opt_target_tasks = 0, opt_paths_per_lane = 0, opt_node_steps = 0, opt_chain_blocks_per_cu = 0;
     int opt_shade_batch = 0, opt_leaf_batch = 0;
+    int opt_block_waves = 0; // RT_OPT_BLOCK_WAVES: waves of the block kernel's block (0: by the size of the launch)
     int opt_lanes_regroup = -1, opt_regroup_rounds = 0; // RT_OPT_LANES_REGROUP (-1: the library's choice), RT_OPT_REGROUP_ROUNDS
 };
 
@@ -1837,7 +1838,13 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
     const bool lanes_block = use_fast && !s->fast_ok && s->lanes_ok && s->lanes_small && p->max_depth < 65536 &&
                              (s->opt_lanes_regroup < 0 ? RT_LANES_REGROUP_DEFAULT : s->opt_lanes_regroup) != 0;
     const bool tile16 = block_kernel || lanes_block;
-    const int tile_w = block_kernel ? 4 * BLOCK_WAVES : tile16 ? 16 : 8, tile_h = tile16 ? 16 : 8, waves_per_task = block_kernel ? BLOCK_WAVES : tile16 ? 4 : 1;
+    // The block kernel's block is four waves (a 16x16 tile) or, for large chained launches, eight (32x16): fewer of its waves sit
+    // at the borders between the classes of the exchange (Cornell 1024x1024: +1 % at 1024 spp, +2.2 % at 128 spp; 512x512x64 spp
+    // -6 %: the last blocks of a small launch are larger).  RT_OPT_BLOCK_WAVES says which; 0: by the number of paths.
+    const int64_t launch_paths = (int64_t)p->nx * p->ny * ns * p->sub_samples;
+    const int block_waves = !block_kernel ? BLOCK_WAVES : s->opt_block_waves > 0 ? s->opt_block_waves
+                            : (s->opt_chain != 0 && launch_paths >= ((int64_t)1 << 27)) ? 2 * BLOCK_WAVES : BLOCK_WAVES;
+    const int tile_w = block_kernel ? 4 * block_waves : tile16 ? 16 : 8, tile_h = tile16 ? 16 : 8, waves_per_task = block_kernel ? block_waves : tile16 ? 4 : 1;
     RenderArgs A{};
     A.nx = p->nx, A.ny = p->ny;
     A.tiles_x = (p->nx + tile_w - 1) / tile_w, A.tiles_y = (p->ny + tile_h - 1) / tile_h;
@@ -1952,9 +1959,14 @@ extern "C" int rt_render(rt_scene *s, const rt_render_params *p, float *d_accum,
 #undef RT_LAUNCH_LANES
     } else if (use_fast && block_kernel && chain) {
         // as many blocks as the chip holds at once (eight per CU); each takes tasks from the counter until none is left
-        const dim3 g((unsigned)std::min<int64_t>(A.n_tasks, (int64_t)s->n_cus * RT_BLOCK_WAVES_PER_EU)), b(64 * BLOCK_WAVES);
+        const int64_t per_cu = RT_BLOCK_WAVES_PER_EU * 4 / block_waves;
+        const dim3 g((unsigned)std::min<int64_t>(A.n_tasks, (int64_t)s->n_cus * per_cu)), b(64 * block_waves);
         RT_HIP(hipMemsetAsync(d_task_counter, 0, sizeof(unsigned), stream));
-        if (s->fast_flat)
+        if (block_waves == 2 * BLOCK_WAVES && s->fast_flat)
+            hipLaunchKernelGGL((render_fast_block_kernel<true, 2 * BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
+        else if (block_waves == 2 * BLOCK_WAVES)
+            hipLaunchKernelGGL((render_fast_block_kernel<false, 2 * BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
+        else if (s->fast_flat)
             hipLaunchKernelGGL((render_fast_block_kernel<true, BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
         else
             hipLaunchKernelGGL((render_fast_block_kernel<false, BLOCK_WAVES, true>), g, b, 0, stream, s->dev, s->d_records, s->layout, A, d_accum, d_task_counter);
@@ -2193,6 +2205,11 @@ extern "C" int rt_scene_set_option(rt_scene *s, int option, int value)
     case RT_OPT_LEAF_BATCH:
         if (value > 64) return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: a batch is at most the 64 lanes of a wave");
         (option == RT_OPT_SHADE_BATCH ? s->opt_shade_batch : s->opt_leaf_batch) = value;
+        return RT_OK;
+    case RT_OPT_BLOCK_WAVES:
+        if (value != 0 && value != BLOCK_WAVES && value != 2 * BLOCK_WAVES)
+            return rt_fail(RT_ERR_INVALID, "rt_scene_set_option: the block kernel's block has %d or %d waves (0: by the size of the launch)", BLOCK_WAVES, 2 * BLOCK_WAVES);
+        s->opt_block_waves = value;
         return RT_OK;
     case RT_OPT_LANES_REGROUP: s->opt_lanes_regroup = value != 0; return RT_OK;
     case RT_OPT_REGROUP_ROUNDS:

@@ -212,10 +212,14 @@ def test_block_kernel_and_wave_kernel_trace_the_same_paths(cornell_gpu):
     cornell_gpu.set_option(_capi.RT_OPT_BLOCK_KERNEL, 0)
     wave = gpu_render(cornell_gpu, nx, ny, 0, ns, sub_samples=2, max_depth=50, seed=6)
     cornell_gpu.set_option(_capi.RT_OPT_BLOCK_KERNEL, 1)
-    assert np.all(block[..., 0] == ns) and np.all(wave[..., 0] == ns)
-    close = np.isclose(block[..., 1:], wave[..., 1:], rtol=1e-4, atol=1e-5).all(axis=-1)
-    assert close.mean() >= 0.995, f"only {close.mean():.4f} of pixels agree"
-    assert np.allclose(block[..., 1:].mean(axis=(0, 1)), wave[..., 1:].mean(axis=(0, 1)), rtol=1e-3)
+    cornell_gpu.set_option(_capi.RT_OPT_BLOCK_WAVES, 8)  # the eight-wave block of large launches (32x16 tiles), forced at this size
+    block8 = gpu_render(cornell_gpu, nx, ny, 0, ns, sub_samples=2, max_depth=50, seed=6)
+    cornell_gpu.set_option(_capi.RT_OPT_BLOCK_WAVES, 0)
+    assert np.all(block[..., 0] == ns) and np.all(wave[..., 0] == ns) and np.all(block8[..., 0] == ns)
+    for other in (wave, block8):
+        close = np.isclose(block[..., 1:], other[..., 1:], rtol=1e-4, atol=1e-5).all(axis=-1)
+        assert close.mean() >= 0.995, f"only {close.mean():.4f} of pixels agree"
+        assert np.allclose(block[..., 1:].mean(axis=(0, 1)), other[..., 1:].mean(axis=(0, 1)), rtol=1e-3)
 
 
 @pytest.mark.parametrize("scene,nx,ny,ns", [("cornell_box", 100, 60, 40), ("cornell_box", 16, 16, 3), ("random_spheres", 72, 40, 24),
