@@ -124,6 +124,7 @@ struct Walk {
                    // cancel to NaN; min/max drop a NaN, which only ever makes a box easier to enter.
     uint32_t rx, ry, rz; // 16 where the direction is negative on that axis, else 0: how far walk_node rotates a node's plane
                          // pairs so that the plane met first is in the low half (rt_bvh.h)
+    int tos;             // `int *` stacks: the top of the stack, in a register (walk_push / walk_pop below)
 };
 // what a walk keeps about its ray (also made again when a walk under way moves to another lane)
 RTF_DEV void walk_ray_constants(Walk &w, const Ray &wr)
@@ -136,6 +137,7 @@ RTF_DEV void walk_start(Walk &w, const Ray &wr, float t_max, bool go)
 {
     w.cur = go ? 0 : RT_BVH_NONE;
     w.sp = 0;
+    w.tos = RT_BVH_NONE;
     w.best_t = t_max;
     w.best_prim = -1;
     walk_ray_constants(w, wr);
@@ -153,8 +155,26 @@ struct HomeStack16 {
 };
 RTF_DEV void stack_push(HomeStack16 st, int &sp, int ref) { st.base[sp++ * st.stride] = (short)ref; }
 RTF_DEV int stack_pop(HomeStack16 st, int &sp) { return sp > 0 ? (int)st.base[--sp * st.stride] : RT_BVH_NONE; }
-template <class ST>
-RTF_DEV int walk_pop(Walk &w, ST stack) { return stack_pop(stack, w.sp); }
+// The walk's own push and pop.  With an `int *` stack the TOP of the stack lives in a register (w.tos): a pop hands it over at once
+// and refills it from LDS while the popped node is being fetched from memory -- read straight from LDS, every pop put an LDS
+// round trip in front of that fetch.  What the first push writes to LDS is the empty top, RT_BVH_NONE, so the stack's floor is
+// its own sentinel and the levels needed stay the same (the entry in the register is the one the sentinel takes the place of).
+// A pop from an empty stack returns RT_BVH_NONE and leaves w.tos to be reset by the next walk_start.
+RTF_DEV void walk_push(Walk &w, int *stack, int ref)
+{
+    stack[w.sp++ * 64] = w.tos;
+    w.tos = ref;
+}
+RTF_DEV int walk_pop(Walk &w, const int *stack)
+{
+    int r = w.tos;
+    asm volatile("" : "+v"(r)); // (the copy is made before the read is issued, so that the read can land in w.tos's register and nothing waits for it here)
+    w.sp = (int)__builtin_elementwise_sub_sat((unsigned)w.sp, 1u);
+    w.tos = stack[w.sp * 64];
+    return r;
+}
+RTF_DEV void walk_push(Walk &w, HomeStack16 stack, int ref) { stack_push(stack, w.sp, ref); }
+RTF_DEV int walk_pop(Walk &w, HomeStack16 stack) { return stack_pop(stack, w.sp); }
 
 // t of the plane stored as a half in the low / high 16 bits of w: ONE v_fma_mix_f32 (half * float + float)
 RTF_DEV float plane_lo(uint32_t w, float inv, float noi) { return fmaf(__half2float(__ushort_as_half((unsigned short)(w & 0xffffu))), inv, noi); }
@@ -193,7 +213,7 @@ RTF_DEV void walk_node(const DevScene &S, Walk &w, float t_min, ST stack)
     const bool first0 = __builtin_amdgcn_inverse_ballot_w64(m0 & (~m1 | nearer0));
     const int near = first0 ? ref0 : ref1, far = first0 ? ref1 : ref0;
     const bool hit_near = __builtin_amdgcn_inverse_ballot_w64(m0 | m1), hit_far = __builtin_amdgcn_inverse_ballot_w64(m0 & m1);
-    if (hit_far) stack_push(stack, w.sp, far);
+    if (hit_far) walk_push(w, stack, far);
     int next = near;
     if (!hit_near) next = walk_pop(w, stack);
     w.cur = next;
