@@ -24,6 +24,11 @@ def test_trees_hold_every_primitive_inside_conservative_boxes(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "half rounding: 0 bad" in p.stdout and "failures: 0" in p.stdout
     assert p.stdout.count("ok=1") == len(SCENES)
+    # a scene-wide item sits beside the root (the builder's "largest item alone" candidate): the fog of Next-Week final, the
+    # ground sphere of the book-1 scene
+    for name in ("next_week_final", "random_spheres"):
+        if name in SCENES:
+            assert f"{name}: root children LEAF / node" in p.stdout or f"{name}: root children node / LEAF" in p.stdout
 
 
 def test_record_tables_of_small_scenes(tmp_path):
