@@ -748,6 +748,25 @@ def test_baseline_configs_1_and_3_at_their_full_image_size(scene, nx, ny):
     assert np.allclose(m_full, m_small, rtol=0.05), (m_full, m_small)
 
 
+def test_headline_size_takes_the_eight_wave_block_and_equals_the_four_wave_image():
+    """BASELINE.json configs[1] at its full image size (Cornell 1024 x 1024), 128 spp: a launch of 2^27 paths, which AUTO runs
+    on the block kernel with blocks of eight waves (32 x 16 tiles).  Every pixel gets its samples, nothing is NaN or negative,
+    and the image is that of the four-wave blocks (RT_OPT_BLOCK_WAVES = 4) up to float summation order -- paths are keyed by
+    (pixel, sample), whatever the block that traces them."""
+    nx = ny = 1024
+    spp = 128
+    sc = Scene(HostScene("cornell_box", 1.0), 0)
+    eight = gpu_render(sc, nx, ny, 0, spp, seed=4)
+    assert sc.info(_capi.RT_INFO_LAST_RENDER_PATH) == _capi.RT_PATH_FAST
+    sc.set_option(_capi.RT_OPT_BLOCK_WAVES, 4)
+    four = gpu_render(sc, nx, ny, 0, spp, seed=4)
+    sc.close()
+    assert np.all(eight[..., 0] == spp) and np.isfinite(eight).all() and (eight[..., 1:] >= 0).all()
+    close = np.isclose(eight[..., 1:], four[..., 1:], rtol=2e-4, atol=1e-3).all(axis=-1)
+    assert close.mean() >= 0.999, f"only {close.mean():.5f} of pixels agree"
+    assert np.allclose(eight[..., 1:].mean(axis=(0, 1)), four[..., 1:].mean(axis=(0, 1)), rtol=1e-4)
+
+
 @pytest.mark.parametrize("scene,lo,hi", [("cornell_box_volumes", 0.0, 555.0), ("next_week_final", 0.0, 555.0)])
 def test_fast_path_medium_free_flight_has_the_oracles_distribution(scene, lo, hi):
     """constant_medium::hit (src/volume.h:23-53) on the per-lane fast path, where it is NOT the exact path's code: the boundary's
