@@ -307,7 +307,7 @@ int rt_trace_rays_noalloc(rt_scene* scene, int32_t n, const float* h_rays, float
  *   RT_EVAL_ONB         in n[3]   out rt:: onb u, v, w (src/vec3.h:195-224), unit(n), get_sphere_uv(unit(n)) (src/utils.h:57-68)
  *   RT_EVAL_ONB_FAST    in n[3], a[3]   out rtf:: onb u, v, w, unit(n), onb.local(a)
  *   RT_EVAL_OPTICS      in v[3], n[3], ni_over_nt, cosine, ref_idx   out reflect[3], refracted?, refract[3], schlick (src/utils.h:4-30)
- *   RT_EVAL_PERLIN      in p[3]   out rt:: noise, turb(7) (src/perlin.h:54-136), rtf:: noise, turb
+ *   RT_EVAL_PERLIN      in p[3]   out rt:: noise, turb(7) (src/perlin.h:54-136), rtf:: noise, turb (corner loop), rtf:: noise, turb (corners written out)
  *   RT_EVAL_TEXTURE     in index into the scene's textures, u, v, p[3]   out rt:: value[3] (src/texture.h:9-81), rtf:: value[3], rtf::wave_noise_value (noise textures; else 0)
  *   RT_EVAL_SAMPLERS    in key, pixel (bit patterns of the stream, include/rt_rng.h), o[3]; each sampler from draw 0
  *                       out rt:: hitable_list::random(o) over the scene's important list[3] (src/hitable_list.h:79-88),

@@ -350,13 +350,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void render_fast_kernel(DevSc
             V3 T2 = T, L2;
             int depth2 = depth;
             Rng rng2{rng.x ^ 0x5bd1e995u, rng.w};
-            const bool g2 = rtf::shade<TEX>(S, recs, Y, rec >= 0, sf, r2, T2, depth2, A.max_depth, rng2, L2);
+            const bool g2 = rtf::shade<TEX, TEX>(S, recs, Y, rec >= 0, sf, r2, T2, depth2, A.max_depth, rng2, L2);
             keep = (g2 ? r2.d.x + T2.y : L2.z) * 1e-30f;
         }
 #endif
         if (alive) {
             V3 L;
-            if (!rtf::shade<TEX>(S, recs, Y, rec >= 0, sf, r, T, depth, A.max_depth, rng, L)) {
+            // (this kernel has the registers for the perlin corners written out: two_perlin_spheres spends most of its time there)
+            if (!rtf::shade<TEX, TEX>(S, recs, Y, rec >= 0, sf, r, T, depth, A.max_depth, rng, L)) {
                 alive = false;
                 if (L.x == L.x && L.x != 0.0f) atomicAdd(&acc[pix], L.x);
                 if (L.y == L.y && L.y != 0.0f) atomicAdd(&acc[64 + pix], L.y);
@@ -1338,6 +1339,7 @@ __global__ __launch_bounds__(256) void debug_eval_kernel(DevScene S, const uint3
         const V3 p = v3(in[0], in[1], in[2]);
         o16[0] = perlin_noise(S, p), o16[1] = perlin_turb(S, p);
         o16[2] = rtf::fast_perlin_noise(p), o16[3] = rtf::fast_perlin_turb(p);
+        o16[4] = rtf::fast_perlin_noise<true>(p), o16[5] = rtf::fast_perlin_turb<true>(p); // the corners written out (record-table kernel)
     } else if (kind == RT_EVAL_TEXTURE) {
         // in: texture index of the scene's table, u, v, p  out: rt::tex_value, rtf::fast_tex_value
         const int idx = (int)in[0];

@@ -111,6 +111,8 @@ def test_perlin_noise_and_turbulence_on_the_device(kat, cornell):
     out = api.debug_eval(sc, _capi.RT_EVAL_PERLIN, it)
     assert np.array_equal(bits(out[:, 0]), bits(k[:, 3])) and np.array_equal(bits(out[:, 1]), bits(k[:, 4]))
     assert np.allclose(out[:, 2], k[:, 3], rtol=1e-5, atol=2e-6) and np.allclose(out[:, 3], k[:, 4], rtol=1e-5, atol=4e-6)
+    # the fast family's second form (eight corners written out: the record-table kernel for textured scenes)
+    assert np.allclose(out[:, 4], k[:, 3], rtol=1e-5, atol=2e-6) and np.allclose(out[:, 5], k[:, 4], rtol=1e-5, atol=4e-6)
 
 
 def test_textures_on_the_device(kat, cornell):
